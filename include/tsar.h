@@ -1,0 +1,205 @@
+/*
+ * tsar.h — C ABI of the MI355X-native PatchMatch-MVS matcher (libtsar_hip.so).
+ *
+ * This is the drop-in boundary for the GPU operator layer of ZhenlongYuan/TSAR-MVS.
+ * The reference crosses host→device at four C++ functions taking a CUDA-managed
+ * `GlobalState&` (reference gipuma.h:2-6, bodies gipuma.cu:1700-1913) plus the gSLICr
+ * `core_engine` (reference gSLICr_Lib/engines/gSLICr_core_engine.h:19-32).  A managed-memory
+ * C++ object cannot cross an FFI, so the same operators are exported here as plain
+ * `extern "C"` functions over an opaque context, plain pointers and sizes:
+ *
+ *   reference operator (file:line)                      this header
+ *   --------------------------------------------------  ---------------------------------------
+ *   GlobalState ctor + LineState::resize                 tsar_create / tsar_destroy
+ *     (globalstate.h:41-53, linestate.h:71-110)
+ *   getCameraParameters + addImageToTextureFloatGray     tsar_set_views
+ *     (cameraGeometryUtils.h:174-364, main.cpp:1190-1228)
+ *   AlgorithmParameters fill (main.cpp:1386-1416)        tsar_set_params
+ *   viewSelectionSubset fill (main.cpp:1351-1384)        tsar_set_view_subset
+ *   gipuma_init_cu2            (gipuma.cu:678-729)       tsar_pm_init
+ *   red/black prop+refine loop (gipuma.cu:1744-1754,     tsar_pm_iterate
+ *     bodies :846-1138)
+ *   pmCostMultiview_cu on a given plane map              tsar_pm_cost_planes (test / diagnostics hook)
+ *     (gipuma.cu:455-518)
+ *   host fill of norm4/depth/c + firstcuda               tsar_load_planes
+ *     (main.cpp:1479-1493, gipuma_get_disp gipuma.cu:731-755)
+ *   weak.png → lines->scale (main.cpp:1499-1514)         tsar_set_reliable_mask
+ *   gipuma_getlrdiff           (gipuma.cu:1160-1186)     tsar_lrdiff
+ *   sliccuda → gipuma_getview  (gipuma.cu:1188-1213)     tsar_getview
+ *   gipuma_WMF / gipuma_WMF_Final (gipuma.cu:1294-1698)  tsar_wmf
+ *   texture() output canny[]/text[] (main.cpp:559-593)   tsar_set_regions
+ *   CPU RANSAC per region      (main.cpp:1520-1730)      tsar_ransac_regions
+ *   fakecuda → gipuma_update_scale_2 (gipuma.cu:1261-92) tsar_fake_depth
+ *   fillcuda → gipuma_update_scale + gipuma_compute_disp tsar_fill_textureless
+ *     (gipuma.cu:1215-1259, 810-844)
+ *   gipuma_compute_disp alone  (gipuma.cu:810-844)       tsar_compute_disp
+ *   gipuma_compute_disp_final  (gipuma.cu:757-808)       tsar_compute_disp_final
+ *   gipuma_dptow               (gipuma.cu:1140-1158)     tsar_depth_to_plane
+ *   copy-out of norm4 (main.cpp:1785-1795)               tsar_get_result / tsar_get_plane
+ *   gSLICr core_engine::Process_Frame + Get_Seg_Res      tsar_slic
+ *
+ * Conventions
+ *   - every function returns an int status (TSAR_OK = 0, negative = error) and never exits the
+ *     process (the reference's checkCudaErrors calls exit(), helper_cuda.h);
+ *     tsar_last_error() returns a human-readable message for the last failure on that context.
+ *   - the caller owns every buffer it passes; the library owns all device memory inside tsar_ctx.
+ *   - `mem` arguments say where caller buffers live: TSAR_MEM_HOST or TSAR_MEM_DEVICE (HIP device
+ *     pointer on the context's device).  No unified memory.
+ *   - one tsar_ctx per device and per host thread; all work of a context is issued on one HIP
+ *     stream (tsar_get_stream) and the call returns after that work is complete unless the
+ *     function says it is asynchronous.
+ *   - images are row-major float32 gray, values as produced by an 8-bit decode (0..255); planes are
+ *     row-major float32 [h][w] (or [h][w][3]/[h][w][4]).
+ */
+#ifndef TSAR_H_
+#define TSAR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSAR_MAX_VIEWS 64        /* reference MAX_IMAGES 512 (config.h:2); ≤32 views are ever selected */
+#define TSAR_MAXCOST 2.0f        /* reference config.h:22 */
+
+/* status codes */
+#define TSAR_OK 0
+#define TSAR_ERR_INVALID (-1)    /* bad argument */
+#define TSAR_ERR_HIP (-2)        /* HIP runtime failure */
+#define TSAR_ERR_STATE (-3)      /* call order violated (e.g. iterate before set_views) */
+#define TSAR_ERR_NOMEM (-4)
+
+#define TSAR_MEM_HOST 0
+#define TSAR_MEM_DEVICE 1
+
+/* cost combination, reference algorithmparameters.h:17 */
+#define TSAR_COMB_ALL 0
+#define TSAR_COMB_BEST_N 1
+
+/* behaviour flags (tsar_params.flags).  Default 0 = the reference's behaviour wherever it is
+ * well defined. */
+#define TSAR_FLAG_FIX_DOWN_FAR_SEED  (1u << 0) /* seed the down_far arm's minimum with c[down_far]
+                                                  (reference seeds with c[up_far], gipuma.cu:906) */
+#define TSAR_FLAG_FIX_RIGHT_FAR_CMP  (1u << 1) /* right_far arm picks the minimum
+                                                  (reference comparison is inverted, gipuma.cu:943) */
+#define TSAR_FLAG_STRICT_DIV         (1u << 2) /* IEEE divisions in the per-tap perspective divide
+                                                  (bit-exact against the CPU oracle; slower) */
+
+typedef struct tsar_ctx tsar_ctx;
+
+/* One calibrated view as read from an MVSNet-style cams/%08d_cam.txt (reference
+ * fileIoUtils.h:117-153): intrinsics and world→camera extrinsics.  Row-major. */
+typedef struct tsar_camera {
+    float K[9];
+    float R[9];
+    float t[3];
+} tsar_camera;
+
+/* Subset of the reference's AlgorithmParameters (algorithmparameters.h:54-88) that the GPU path
+ * reads.  Zero-initialise, then tsar_default_params(). */
+typedef struct tsar_params {
+    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19) */
+    int32_t box_vsize;
+    int32_t n_best;       /* --n_best (scripts 1; default 2) */
+    int32_t cost_comb;    /* --cost_comb: TSAR_COMB_* */
+    float depth_min;      /* from the reference view's cam file */
+    float depth_max;
+    float cam_scale;      /* --cam_scale: K is divided by it (cameraGeometryUtils.h:143-154) */
+    uint32_t flags;       /* TSAR_FLAG_* */
+    uint64_t seed;        /* RNG stream seed (the reference seeds with clock64(), gipuma.cu:700) */
+} tsar_params;
+
+/* gSLICr settings actually set by the reference (main.cpp:608-615). */
+typedef struct tsar_slic_settings {
+    int32_t spixel_size;      /* 20 */
+    int32_t no_iters;         /* 5 */
+    float coh_weight;         /* 5.0 */
+    int32_t do_enforce_connectivity; /* 0 in the reference */
+    int32_t color_space;      /* 0 = CIELAB (reference), 1 = XYZ, 2 = RGB */
+} tsar_slic_settings;
+
+/* Per-kernel timing record (tsar_get_kernel_timing). */
+typedef struct tsar_kernel_timing {
+    char name[48];
+    int32_t launches;
+    float total_ms;           /* sum of hipEventElapsedTime over the launches */
+} tsar_kernel_timing;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int tsar_create(int device, tsar_ctx** out);
+int tsar_destroy(tsar_ctx* ctx);
+const char* tsar_last_error(const tsar_ctx* ctx);
+const char* tsar_version(void);
+/* the HIP stream (hipStream_t) all kernels of this context are launched on */
+int tsar_get_stream(tsar_ctx* ctx, void** stream_out);
+int tsar_synchronize(tsar_ctx* ctx);
+
+/* ---- inputs ---------------------------------------------------------------------------- */
+void tsar_default_params(tsar_params* p);
+int tsar_set_params(tsar_ctx* ctx, const tsar_params* p);
+/* views[0] is the reference view, views[1..n-1] the source views, in the order of the reference's
+ * argv image list.  gray[i] points at w*h float32.  Cameras are re-origined so that the reference
+ * camera is K[I|0] (cameraGeometryUtils.h:270-302).  Must follow tsar_set_params. */
+int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem,
+                   const tsar_camera* cams);
+/* indices (1..n_views-1) of the source views used for matching, in pair.txt order.
+ * Default after tsar_set_views: all source views. */
+int tsar_set_view_subset(tsar_ctx* ctx, int n, const int32_t* view_idx);
+
+/* ---- PatchMatch (the north-star path) --------------------------------------------------- */
+int tsar_pm_init(tsar_ctx* ctx);
+/* `iters` red/black iterations; each = black (prop+refine) then red (prop+refine). */
+int tsar_pm_iterate(tsar_ctx* ctx, int iters);
+/* Diagnostics: multi-view cost of caller-supplied planes.  planes = [h][w][4] (n_x,n_y,n_z,d) in
+ * reference-camera coordinates; outputs [h][w]; beview/ratio may be NULL. */
+int tsar_pm_cost_planes(tsar_ctx* ctx, const float* planes, int mem, float* cost_out,
+                        int32_t* beview_out, float* ratio_out);
+/* Diagnostics: overwrite / read the raw matcher state: planes [h][w][4] + cost [h][w]. */
+int tsar_set_plane(tsar_ctx* ctx, const float* planes, const float* cost, int mem);
+int tsar_get_plane(tsar_ctx* ctx, float* planes, float* cost, int32_t* beview, float* ratio, int mem);
+
+/* ---- plane <-> depth (reference gipuma.cu:731-844, 1140-1158) ---------------------------- */
+/* depth [h][w], normal_world [h][w][3]: planes from an external MVS; cost is set to 1. */
+int tsar_load_planes(tsar_ctx* ctx, const float* depth, const float* normal_world, int mem);
+int tsar_compute_disp(tsar_ctx* ctx);
+int tsar_compute_disp_final(tsar_ctx* ctx, const float* resize_planes, const float* text, int mem);
+int tsar_depth_to_plane(tsar_ctx* ctx);
+/* After tsar_compute_disp: depth [h][w] (0 where cost == MAXCOST), normal_world [h][w][3],
+ * cost [h][w], confid [h][w]; any may be NULL. */
+int tsar_get_result(tsar_ctx* ctx, float* depth, float* normal_world, float* cost, float* confid,
+                    int mem);
+
+/* ---- TSAR textureless refinement (reference gipuma.cu:1160-1698, main.cpp:1499-1783) ------ */
+int tsar_set_reliable_mask(tsar_ctx* ctx, const float* scale, int mem);          /* lines->scale */
+int tsar_lrdiff(tsar_ctx* ctx);
+int tsar_getview(tsar_ctx* ctx);
+int tsar_wmf(tsar_ctx* ctx, int iters, int final_pass);
+/* labels [h][w] = region id per pixel (lines->canny); region_text[n_regions] = -1 for textureless
+ * regions (cannylines->text). */
+int tsar_set_regions(tsar_ctx* ctx, const int32_t* labels, int n_regions, const float* region_text,
+                     const float* region_size, int mem);
+/* GPU replacement of the per-region CPU RANSAC; region_planes_out [n_regions][4] may be NULL */
+int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, float* inlier_ratio_out);
+int tsar_set_region_planes(tsar_ctx* ctx, const float* region_planes);            /* host [n][4] */
+int tsar_fake_depth(tsar_ctx* ctx, float* fakedepth_out, int mem);
+int tsar_fill_textureless(tsar_ctx* ctx);
+
+/* ---- gSLICr superpixels ------------------------------------------------------------------ */
+void tsar_default_slic_settings(tsar_slic_settings* s);
+/* bgra: [h][w][4] uint8 (the reference feeds a 1/4-resolution BGR image, main.cpp:617-640);
+ * labels_out [h][w] int32. */
+int tsar_slic(tsar_ctx* ctx, const uint8_t* bgra, int w, int h, const tsar_slic_settings* s,
+              int32_t* labels_out, int mem);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the context's stream. */
+int tsar_enable_kernel_timing(tsar_ctx* ctx, int enable);
+int tsar_reset_kernel_timing(tsar_ctx* ctx);
+/* fills up to `cap` records, returns the number of distinct kernels in *n_out */
+int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSAR_H_ */

@@ -1,0 +1,803 @@
+/*
+ * tsar_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the PatchMatch / TSAR hot path of ZhenlongYuan/TSAR-MVS
+ * (reference gipuma.cu, main.cpp).  Nothing under oracle/ is linked, imported or executed by the
+ * product (libtsar_hip.so, tsar_mvs_amd/); only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may use it, and only as the checker / the reported CPU baseline.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or sample outputs and
+ * cannot be built in this image (it needs nvcc, the CUDA headers/runtime, cuRAND and OpenCV; none
+ * are present and stand-ins for them are not allowed).  This file is therefore pinned only by
+ * analytic known answers authored in tests/ (a plane that truly generated the images scores ~0,
+ * homography of a fronto-parallel plane is the expected translation, plane<->depth round trips,
+ * etc.), not by outputs of the reference itself.
+ *
+ * Each function cites the reference lines it restates.  Where the reference is non-deterministic
+ * or undefined, the deterministic semantics chosen are:
+ *   S1 RNG: stateless Philox4x32-10, key = seed, counter = (pixel, stream, step, 0); the reference
+ *      re-seeds XORWOW with clock64() in every kernel (gipuma.cu:700,1077).
+ *   S2 propagation reads neighbours from the state as it was when the launch started (Jacobi);
+ *      the reference races on same-colour neighbours (gipuma.cu:958-1034).
+ *   S3 image reads: clamp-to-edge addressing, exact fp32 bilinear weights (CUDA uses 8 fractional
+ *      bits; tex2D does not exist on gfx950).
+ *   S4 fused multiply-adds appear exactly where fmaf() is written here; everything else is a
+ *      single IEEE operation (compile with -ffp-contract=off).  rsqrtf -> 1/sqrtf, exp -> the
+ *      polynomial orc_expf below (both sides of the parity check implement the same polynomial).
+ *   S5 reference quirks 1,2 (down_far seed, inverted right_far compare) are reproduced unless the
+ *      FIX flags are set; the out-of-bounds read of quirk 1 (y<3) is defined as c[down_far].
+ *   S6 ratio = c0/c1 needs two selected views; with one it is defined as 0 (reference reads an
+ *      uninitialised slot, gipuma.cu:505).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -fopenmp -shared).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_VIEWS 64
+#define ORC_MAXCOST 2.0f
+#define ORC_FLAG_FIX_DOWN_FAR_SEED (1u << 0)
+#define ORC_FLAG_FIX_RIGHT_FAR_CMP (1u << 1)
+
+typedef struct {
+    float K[9], Kinv[9], R[9], t[3]; /* pose relative to the reference camera (ref = K[I|0]) */
+    float Minv[9], P34[3], C[3];     /* of P = K_ref [R|t] (cameraGeometryUtils.h:302-356) */
+    float Rorig[9], RorigInv[9];
+    float fx, fy, f, alpha, baseline, depthMin, depthMax;
+} orc_camera;
+
+typedef struct {
+    int w, h, n_views;
+    const float *img[ORC_MAX_VIEWS];
+    orc_camera cam[ORC_MAX_VIEWS];
+    int n_sel, sel[ORC_MAX_VIEWS];
+    int hrad, vrad, n_best, cost_comb;
+    float min_disp, max_disp;
+    uint32_t flags;
+    uint64_t seed;
+    /* LineState planes (linestate.h:12-47) */
+    float *c, *norm4, *ratio, *depth, *scale, *lrdiff, *confid, *fakedepth;
+    int32_t *beview, *canny;
+    /* cannylines */
+    int n_regions;
+    float *region_text, *region_norm4, *region_size;
+    int launch; /* number of red/black launches so far (RNG stream) */
+} orc_state;
+
+/* ------------------------------------------------------------------------------------------ */
+/* small algebra (config.h:36-241)                                                              */
+static inline float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+static inline void mat3vec(const float *m, const float *v, float *o) {
+    o[0] = dot3f(m, v);
+    o[1] = dot3f(m + 3, v);
+    o[2] = dot3f(m + 6, v);
+}
+static inline void mat3mul(const float *a, const float *b, float *o) { /* matmul_cu config.h:204-240 */
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            o[r * 3 + c] = fmaf(a[r * 3 + 2], b[6 + c], fmaf(a[r * 3 + 1], b[3 + c], a[r * 3] * b[c]));
+}
+
+/* exp() for x <= 0 (bilateral weight, gipuma.cu:268): Cody-Waite reduction + Cephes polynomial. */
+float orc_expf(float x) {
+    x = fmaxf(x, -87.0f);
+    float k = rintf(x * 1.44269504f);
+    float r = fmaf(k, -0.693145752f, x);
+    r = fmaf(k, -1.42860677e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p, r * r, r) + 1.0f;
+    union { uint32_t u; float f; } s;
+    s.u = (uint32_t)((int32_t)k + 127) << 23;
+    return y * s.f;
+}
+
+/* Philox4x32-10 (Salmon et al. 2011), S1 */
+static inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* (0,1] like curand_uniform */
+static inline float u01(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-8f; }
+static inline void rng4(const orc_state *s, uint32_t pixel, uint32_t stream, uint32_t step, float u[4]) {
+    uint32_t r[4];
+    philox4x32(pixel, stream, step, 0u, (uint32_t)s->seed, (uint32_t)(s->seed >> 32), r);
+    for (int i = 0; i < 4; i++) u[i] = u01(r[i]);
+}
+void orc_rng4(uint64_t seed, uint32_t pixel, uint32_t stream, uint32_t step, float *u) {
+    orc_state s;
+    s.seed = seed;
+    rng4(&s, pixel, stream, step, u);
+}
+/* curand_between gipuma.cu:113-116 */
+static inline float between(float u, float lo, float hi) { return fmaf(u, hi - lo, lo); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* image access, S3                                                                            */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float texel(const float *img, int w, int h, int x, int y) {
+    return img[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)];
+}
+/* tex2D<float>(tex, u+0.5, v+0.5) with linear filtering, clamp addressing (main.cpp:1215-1219) */
+static inline float bilinear(const float *img, int w, int h, float u, float v) {
+    u = fminf(fmaxf(u, -1.0f), (float)w);
+    v = fminf(fmaxf(v, -1.0f), (float)h);
+    float fu = floorf(u), fv = floorf(v);
+    float ax = u - fu, ay = v - fv;
+    int x0 = (int)fu, y0 = (int)fv;
+    float t00 = texel(img, w, h, x0, y0), t10 = texel(img, w, h, x0 + 1, y0);
+    float t01 = texel(img, w, h, x0, y0 + 1), t11 = texel(img, w, h, x0 + 1, y0 + 1);
+    float top = fmaf(ax, t10 - t00, t00);
+    float bot = fmaf(ax, t11 - t01, t01);
+    return fmaf(ay, bot - top, top);
+}
+float orc_bilinear(const float *img, int w, int h, float u, float v) { return bilinear(img, w, h, u, v); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* camera derivation (cameraGeometryUtils.h:270-356), double precision then rounded            */
+static void inv3d(const double *m, double *o) {
+    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    double id = 1.0 / det;
+    o[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+static void mul3d(const double *a, const double *b, double *o) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+}
+/* K,R,t: n_views x (9,9,3) floats, world->camera; view 0 is the reference */
+void orc_derive_cameras(orc_state *s, int n_views, const float *K, const float *R, const float *t, float cam_scale,
+                        float depth_min, float depth_max) {
+    double R0[9], t0[3], K0[9];
+    for (int i = 0; i < 9; i++) { R0[i] = R[i]; K0[i] = K[i]; }
+    for (int i = 0; i < 3; i++) t0[i] = t[i];
+    /* scaleK cameraGeometryUtils.h:143-154 */
+    K0[0] /= cam_scale; K0[4] /= cam_scale; K0[2] /= cam_scale; K0[5] /= cam_scale;
+    s->n_views = n_views;
+    for (int v = 0; v < n_views; v++) {
+        orc_camera *cm = &s->cam[v];
+        double Kv[9], Rv[9], tv[3], Rrel[9], trel[3], R0t[9];
+        for (int i = 0; i < 9; i++) { Kv[i] = K[v * 9 + i]; Rv[i] = R[v * 9 + i]; }
+        for (int i = 0; i < 3; i++) tv[i] = t[v * 3 + i];
+        Kv[0] /= cam_scale; Kv[4] /= cam_scale; Kv[2] /= cam_scale; Kv[5] /= cam_scale;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) R0t[r * 3 + c] = R0[c * 3 + r];
+        mul3d(Rv, R0t, Rrel); /* [R|t] * [R0|t0]^-1 */
+        for (int r = 0; r < 3; r++) trel[r] = tv[r] - (Rrel[r * 3] * t0[0] + Rrel[r * 3 + 1] * t0[1] + Rrel[r * 3 + 2] * t0[2]);
+        if (v == 0) { /* exactly K[I|0] */
+            for (int i = 0; i < 9; i++) Rrel[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            trel[0] = trel[1] = trel[2] = 0.0;
+        }
+        double Kvi[9], M[9], Mi[9], P34[3];
+        inv3d(Kv, Kvi);
+        mul3d(K0, Rrel, M); /* P built with the reference K for every camera (cameraGeometryUtils.h:302) */
+        inv3d(M, Mi);
+        for (int r = 0; r < 3; r++) P34[r] = K0[r * 3] * trel[0] + K0[r * 3 + 1] * trel[1] + K0[r * 3 + 2] * trel[2];
+        for (int i = 0; i < 9; i++) {
+            cm->K[i] = (float)Kv[i]; cm->Kinv[i] = (float)Kvi[i]; cm->R[i] = (float)Rrel[i]; cm->Minv[i] = (float)Mi[i];
+            cm->Rorig[i] = (float)Rv[i];
+        }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) cm->RorigInv[r * 3 + c] = (float)Rv[c * 3 + r];
+        for (int r = 0; r < 3; r++) {
+            cm->t[r] = (float)trel[r];
+            cm->P34[r] = (float)P34[r];
+            cm->C[r] = (float)(-(Rrel[r] * trel[0] + Rrel[3 + r] * trel[1] + Rrel[6 + r] * trel[2]));
+        }
+        cm->fx = (float)K0[0]; cm->fy = (float)K0[4]; cm->f = (float)K0[0];
+        cm->alpha = (float)K0[0] / (float)K0[4];
+        cm->baseline = 1.0f; /* cameraGeometryUtils.h:309 */
+        cm->depthMin = depth_min; cm->depthMax = depth_max;
+    }
+    /* main.cpp:1393-1398 */
+    s->min_disp = s->cam[0].f * s->cam[0].baseline / depth_max;
+    s->max_disp = s->cam[0].f * s->cam[0].baseline / depth_min;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* geometry helpers                                                                            */
+/* getD_cu gipuma.cu:71-86 */
+static inline float getD(const float *n, int x, int y, float depth, const orc_camera *cm) {
+    float pt[3], X[3];
+    pt[0] = depth * (float)x - cm->P34[0];
+    pt[1] = depth * (float)y - cm->P34[1];
+    pt[2] = depth - cm->P34[2];
+    mat3vec(cm->Minv, pt, X);
+    return -dot3f(n, X);
+}
+/* getDepthFromPlane3_cu / getDisparity_cu gipuma.cu:436-453 */
+static inline float depth_from_plane(const orc_camera *cm, const float *n4, int x, int y) {
+    float d = n4[3];
+    if (d != d) return 1000.0f;
+    float den = fmaf(n4[2], cm->fx, fmaf(n4[1] * ((float)y - cm->K[5]), cm->alpha, n4[0] * ((float)x - cm->K[2])));
+    return (-d * cm->fx) / den;
+}
+/* getViewVector_cu gipuma.cu:97-105 (+ get3Dpoint_cu1 :57-67, normalize_cu :88-95) */
+static inline void view_vector(const orc_camera *cm, int x, int y, float *v) {
+    float pt[3], X[3];
+    pt[0] = (float)x - cm->P34[0];
+    pt[1] = (float)y - cm->P34[1];
+    pt[2] = 1.0f - cm->P34[2];
+    mat3vec(cm->Minv, pt, X);
+    X[0] -= cm->C[0]; X[1] -= cm->C[1]; X[2] -= cm->C[2];
+    float inv = 1.0f / sqrtf(dot3f(X, X));
+    v[0] = X[0] * inv; v[1] = X[1] * inv; v[2] = X[2] * inv;
+}
+float orc_getD(const orc_state *s, const float *n, int x, int y, float depth) { return getD(n, x, y, depth, &s->cam[0]); }
+float orc_depth_from_plane(const orc_state *s, const float *n4, int x, int y) { return depth_from_plane(&s->cam[0], n4, x, y); }
+void orc_view_vector(const orc_state *s, int x, int y, float *v) { view_vector(&s->cam[0], x, y, v); }
+
+/* getHomography_cu gipuma.cu:207-224: H = K_to * ((R - t n^T / d) * K_ref^-1) */
+static inline void homography(const orc_camera *ref, const orc_camera *to, const float *n4, float *H) {
+    float inv_d = 1.0f / n4[3];
+    float M[9], T[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) M[r * 3 + c] = to->R[r * 3 + c] - (to->t[r] * n4[c]) * inv_d;
+    mat3mul(M, ref->Kinv, T);
+    mat3mul(to->K, T, H);
+}
+void orc_homography(const orc_state *s, int view, const float *n4, float *H) { homography(&s->cam[0], &s->cam[view], n4, H); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* pmCost gipuma.cu:229-298: bilateral-weighted NCC over the dilated window                     */
+static float pm_cost(const orc_state *s, int view, int x, int y, const float *n4) {
+    const float *l = s->img[0], *r = s->img[view];
+    const int w = s->w, h = s->h;
+    float H[9];
+    homography(&s->cam[0], &s->cam[view], n4, H);
+    float cen = texel(l, w, h, x, y);
+    float sum_ref = 0, sum_ref_ref = 0, sum_src = 0, sum_src_src = 0, sum_ref_src = 0, wsum = 0;
+    for (int i = -s->hrad; i < s->hrad + 1; i += 2) {
+        float xi = (float)(x + i);
+        float bx = fmaf(H[0], xi, H[2]), by = fmaf(H[3], xi, H[5]), bz = fmaf(H[6], xi, H[8]);
+        for (int j = -s->vrad; j < s->vrad + 1; j += 2) {
+            float yj = (float)(y + j);
+            float ref_pix = texel(l, w, h, x + i, y + j);
+            float X = fmaf(H[1], yj, bx), Y = fmaf(H[4], yj, by), Z = fmaf(H[7], yj, bz);
+            float src_pix = bilinear(r, w, h, X / Z, Y / Z);
+            float sd = sqrtf((float)(i * i + j * j));
+            float cd = fabsf(ref_pix - cen);
+            float wt = orc_expf(-sd / 50.0f - cd / 18.0f);
+            float wr = wt * ref_pix, ws = wt * src_pix;
+            sum_ref += wr;
+            sum_ref_ref = fmaf(wr, ref_pix, sum_ref_ref);
+            sum_src += ws;
+            sum_src_src = fmaf(ws, src_pix, sum_src_src);
+            sum_ref_src = fmaf(wr, src_pix, sum_ref_src);
+            wsum += wt;
+        }
+    }
+    float inv = 1.0f / wsum;
+    sum_ref *= inv; sum_ref_ref *= inv; sum_src *= inv; sum_src_src *= inv; sum_ref_src *= inv;
+    float var_ref = sum_ref_ref - sum_ref * sum_ref;
+    float var_src = sum_src_src - sum_src * sum_src;
+    if (var_ref < 1e-5f || var_src < 1e-5f) return ORC_MAXCOST;
+    float covar = sum_ref_src - sum_ref * sum_src;
+    float vrs = sqrtf(var_ref * var_src);
+    return fmaxf(0.0f, fminf(ORC_MAXCOST, 1.0f - covar / vrs));
+}
+float orc_pm_cost(const orc_state *s, int view, int x, int y, const float *n4) { return pm_cost(s, view, x, y, n4); }
+
+/* sort_small gipuma.cu:425-434 */
+static void sort_small(float *d, int n) {
+    for (int i = 1; i < n; i++) {
+        float tmp = d[i];
+        int j;
+        for (j = i; j >= 1 && tmp < d[j - 1]; j--) d[j] = d[j - 1];
+        d[j] = tmp;
+    }
+}
+/* pmCostMultiview_cu gipuma.cu:455-518 */
+static float pm_cost_multiview(const orc_state *s, int x, int y, const float *n4, int *beview, float *ratio) {
+    float cv[ORC_MAX_VIEWS], ov[ORC_MAX_VIEWS];
+    int num = s->n_sel, valid = 0;
+    for (int i = 0; i < num; i++) {
+        float c = pm_cost(s, s->sel[i], x, y, n4);
+        if (c < ORC_MAXCOST) valid++; else c = ORC_MAXCOST;
+        cv[i] = c; ov[i] = c;
+    }
+    sort_small(cv, num);
+    int nb = valid;
+    if (s->cost_comb == 1) nb = nb < s->n_best ? nb : s->n_best;
+    float cost;
+    if (nb > 0) {
+        cost = 0.0f;
+        for (int i = 0; i < nb; i++) cost += cv[i];
+        cost = cost / (float)nb;
+        *ratio = num >= 2 ? cv[0] / cv[1] : 0.0f; /* S6 */
+        *beview = -1;
+        for (int i = 0; i < num; i++)
+            if (cv[0] == ov[i]) *beview = s->sel[i];
+    } else {
+        cost = ORC_MAXCOST; *ratio = 0.0f; *beview = -1;
+    }
+    return cost;
+}
+float orc_pm_cost_multiview(const orc_state *s, int x, int y, const float *n4, int *beview, float *ratio) {
+    return pm_cost_multiview(s, x, y, n4, beview, ratio);
+}
+void orc_pm_cost_planes(const orc_state *s, const float *planes, float *cost, int32_t *beview, float *ratio) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            int bv; float rt;
+            cost[p] = pm_cost_multiview(s, x, y, planes + 4 * p, &bv, &rt);
+            if (beview) beview[p] = bv;
+            if (ratio) ratio[p] = rt;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gipuma_init_cu2 gipuma.cu:678-729 */
+static void init_pixel(orc_state *s, int x, int y) {
+    const orc_camera *cm = &s->cam[0];
+    size_t p = (size_t)y * s->w + x;
+    float vv[3], u[4], n4[4];
+    view_vector(cm, x, y, vv);
+    rng4(s, (uint32_t)p, 0u, 0u, u);
+    float disp = between(u[0], s->min_disp, s->max_disp);
+    /* rndUnitVectorSphereMarsaglia_cu gipuma.cu:118-132 */
+    float a = between(u[1], -1.0f, 1.0f), b = between(u[2], -1.0f, 1.0f);
+    float sum = fmaf(a, a, b * b);
+    for (uint32_t call = 1; sum >= 1.0f && call < 16; call++) {
+        rng4(s, (uint32_t)p, 0u, call, u);
+        a = between(u[0], -1.0f, 1.0f); b = between(u[1], -1.0f, 1.0f);
+        sum = fmaf(a, a, b * b);
+        if (sum >= 1.0f) {
+            a = between(u[2], -1.0f, 1.0f); b = between(u[3], -1.0f, 1.0f);
+            sum = fmaf(a, a, b * b);
+        }
+    }
+    if (sum >= 1.0f) { a = 0.0f; b = 0.0f; sum = 0.0f; }
+    float sq = sqrtf(1.0f - sum);
+    n4[0] = 2.0f * a * sq; n4[1] = 2.0f * b * sq; n4[2] = 1.0f - 2.0f * sum;
+    if (dot3f(n4, vv) > 0.0f) { n4[0] = -n4[0]; n4[1] = -n4[1]; n4[2] = -n4[2]; } /* vecOnHemisphere_cu :106-112 */
+    float depth = cm->f * cm->baseline / disp;
+    n4[3] = getD(n4, x, y, depth, cm);
+    memcpy(s->norm4 + 4 * p, n4, sizeof n4);
+    int bv; float rt;
+    s->c[p] = pm_cost_multiview(s, x, y, n4, &bv, &rt);
+}
+void orc_pm_init(orc_state *s) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) init_pixel(s, x, y);
+    s->launch = 0;
+}
+
+/* candidate selection of gipuma_checkerboard_spatialProp_cu gipuma.cu:874-1042; out[8] = pixel
+ * index per arm (up_far, down_far, left_far, right_far, up_near, down_near, left_near, right_near)
+ * or -1 when the arm is skipped.  c = cost plane of the launch-start snapshot (S2). */
+static void select_candidates(const orc_state *s, const float *c, int x, int y, int32_t *out) {
+    const int col = s->w, row = s->h;
+    const int p = y * col + x;
+    const int left_near = p - 1, left_far = p - 3, right_near = p + 1, right_far = p + 3;
+    const int up_near = p - col, up_far = p - 3 * col, down_near = p + col, down_far = p + 3 * col;
+    float cmin; int cp;
+    for (int k = 0; k < 8; k++) out[k] = -1;
+    if (y > 2) { /* up_far :889-902 */
+        cmin = c[up_far]; cp = up_far;
+        for (int i = 1; i < 11; ++i)
+            if (y > 2 + 2 * i) { int q = up_far - 2 * i * col; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        out[0] = cp;
+    }
+    if (y < row - 3) { /* down_far :905-918, quirk 1 */
+        if ((s->flags & ORC_FLAG_FIX_DOWN_FAR_SEED) || y <= 2) cmin = c[down_far]; else cmin = c[up_far];
+        cp = down_far;
+        for (int i = 1; i < 11; ++i)
+            if (y < row - 3 - 2 * i) { int q = down_far + 2 * i * col; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        out[1] = cp;
+    }
+    if (x > 2) { /* left_far :921-934 */
+        cmin = c[left_far]; cp = left_far;
+        for (int i = 1; i < 11; ++i)
+            if (x > 2 + 2 * i) { int q = left_far - 2 * i; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        out[2] = cp;
+    }
+    if (x < col - 3) { /* right_far :937-950, quirk 2 */
+        cmin = c[right_far]; cp = right_far;
+        for (int i = 1; i < 11; ++i)
+            if (x < col - 3 - 2 * i) {
+                int q = right_far + 2 * i;
+                int take = (s->flags & ORC_FLAG_FIX_RIGHT_FAR_CMP) ? (c[q] < cmin) : (cmin < c[q]);
+                if (take) { cmin = c[q]; cp = q; }
+            }
+        out[3] = cp;
+    }
+    if (y > 0) { /* up_near :953-973 */
+        cmin = c[up_near]; cp = up_near;
+        for (int i = 0; i < 3; ++i) {
+            if (y > 1 + i && x > i) { int q = up_near - (1 + i) * col - i; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+            if (y > 1 + i && x < col - 1 - i) { int q = up_near - (1 + i) * col + i; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        }
+        out[4] = cp;
+    }
+    if (y < row - 1) { /* down_near :976-996 */
+        cmin = c[down_near]; cp = down_near;
+        for (int i = 0; i < 3; ++i) {
+            if (y < row - 2 - i && x > i) { int q = down_near + (1 + i) * col - i; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+            if (y < row - 2 - i && x < col - 1 - i) { int q = down_near + (1 + i) * col + i; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        }
+        out[5] = cp;
+    }
+    if (x > 0) { /* left_near :999-1019 */
+        cmin = c[left_near]; cp = left_near;
+        for (int i = 0; i < 3; ++i) {
+            if (x > 1 + i && y > i) { int q = left_near - (1 + i) - i * col; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+            if (x > 1 + i && y < row - 1 - i) { int q = left_near - (1 + i) + i * col; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        }
+        out[6] = cp;
+    }
+    if (x < col - 1) { /* right_near :1022-1042 */
+        cmin = c[right_near]; cp = right_near;
+        for (int i = 0; i < 3; ++i) {
+            if (x < col - 2 - i && y > i) { int q = right_near + (1 + i) - i * col; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+            if (x < col - 2 - i && y < row - 1 - i) { int q = right_near + (1 + i) + i * col; if (c[q] < cmin) { cmin = c[q]; cp = q; } }
+        }
+        out[7] = cp;
+    }
+}
+void orc_select_candidates(const orc_state *s, const float *c, int x, int y, int32_t *out) { select_candidates(s, c, x, y, out); }
+
+typedef struct { float cost, n4[4], depth, ratio; int beview, wrote; } pix_t;
+
+/* gipuma_checkerboard_spatialProp_cu :846-1050 + spatialPropagation_cu :524-566 */
+static void propagate_pixel(const orc_state *s, const float *c_snap, const float *n_snap, int x, int y, pix_t *px) {
+    const orc_camera *cm = &s->cam[0];
+    int32_t cand[8];
+    select_candidates(s, c_snap, x, y, cand);
+    for (int k = 0; k < 8; k++) {
+        if (cand[k] < 0) continue;
+        const float *nb = n_snap + 4 * (size_t)cand[k];
+        float depth_b = depth_from_plane(cm, nb, x, y);
+        int bv; float rt;
+        float cost_b = pm_cost_multiview(s, x, y, nb, &bv, &rt);
+        if (depth_b >= cm->depthMin && depth_b <= cm->depthMax && cost_b < px->cost) {
+            px->depth = depth_b; memcpy(px->n4, nb, 16); px->cost = cost_b;
+            px->ratio = rt; px->beview = bv; px->wrote = 1;
+        }
+    }
+}
+/* gipuma_checkerboard_planeRefinement_cu :1053-1094, planeRefinement_cu :621-676,
+ * getRndDispAndUnitVector_cu :582-619 */
+static void refine_pixel(const orc_state *s, int x, int y, uint32_t stream, pix_t *px) {
+    const orc_camera *cm = &s->cam[0];
+    size_t p = (size_t)y * s->w + x;
+    float vv[3];
+    view_vector(cm, x, y, vv);
+    float deltaN = 1.0f;
+    const float maxdisp = s->max_disp / 2.0f;
+    uint32_t step = 0;
+    for (float deltaZ = maxdisp; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f, step++) {
+        float u[4], nt[4];
+        rng4(s, (uint32_t)p, stream, step, u);
+        float disp = cm->f * cm->baseline / px->depth;
+        float minDelta = -fminf(deltaZ, s->min_disp + disp); /* quirk 5: plus, as written (:601) */
+        float maxDelta = fminf(deltaZ, s->max_disp - disp);
+        float dz = between(u[0], minDelta, maxDelta);
+        float dispOut = fminf(fmaxf(disp + dz, s->min_disp), s->max_disp);
+        float depthOut = cm->f * cm->baseline / dispOut;
+        nt[0] = px->n4[0] + between(u[1], -deltaN, deltaN);
+        nt[1] = px->n4[1] + between(u[2], -deltaN, deltaN);
+        nt[2] = px->n4[2] + between(u[3], -deltaN, deltaN);
+        float inv = 1.0f / sqrtf(dot3f(nt, nt));
+        nt[0] *= inv; nt[1] *= inv; nt[2] *= inv;
+        if (dot3f(nt, vv) > 0.0f) { nt[0] = -nt[0]; nt[1] = -nt[1]; nt[2] = -nt[2]; }
+        nt[3] = getD(nt, x, y, depthOut, cm);
+        int bv; float rt;
+        float ct = pm_cost_multiview(s, x, y, nt, &bv, &rt);
+        if (ct < px->cost) {
+            px->cost = ct; px->depth = depthOut; memcpy(px->n4, nt, 16);
+            px->ratio = rt; px->beview = bv; px->wrote = 1;
+        }
+        deltaN = deltaN / 4.0f;
+    }
+}
+int orc_refine_steps(const orc_state *s) {
+    int n = 0;
+    for (float deltaZ = s->max_disp / 2.0f; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f) n++;
+    return n;
+}
+
+/* one launch = propagation then refinement of every pixel of one colour.
+ * colour 0 = "black": (x + y) even  (gipuma.cu:1099-1103: even x -> even y, odd x -> odd y),
+ * colour 1 = "red".  do_prop / do_refine allow testing the halves separately. */
+void orc_pm_sweep(orc_state *s, int colour, int do_prop, int do_refine) {
+    const size_t np = (size_t)s->w * s->h;
+    float *c_snap = (float *)malloc(np * sizeof(float));
+    float *n_snap = (float *)malloc(np * 4 * sizeof(float));
+    memcpy(c_snap, s->c, np * sizeof(float));
+    memcpy(n_snap, s->norm4, np * 4 * sizeof(float));
+    const uint32_t stream = 1u + (uint32_t)s->launch;
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            if (((x + y) & 1) != colour) continue;
+            size_t p = (size_t)y * s->w + x;
+            pix_t px;
+            px.cost = c_snap[p]; memcpy(px.n4, n_snap + 4 * p, 16);
+            px.depth = depth_from_plane(&s->cam[0], px.n4, x, y);
+            px.wrote = 0; px.ratio = 0; px.beview = 0;
+            if (do_prop) propagate_pixel(s, c_snap, n_snap, x, y, &px);
+            if (do_refine) refine_pixel(s, x, y, stream, &px);
+            s->c[p] = px.cost; memcpy(s->norm4 + 4 * p, px.n4, 16);
+            if (px.wrote) { s->ratio[p] = px.ratio; s->beview[p] = px.beview; }
+        }
+    free(c_snap); free(n_snap);
+    s->launch++;
+}
+/* host loop of gipuma_first gipuma.cu:1744-1754 */
+void orc_pm_iterate(orc_state *s, int iters) {
+    for (int it = 0; it < iters; it++) {
+        orc_pm_sweep(s, 0, 1, 1);
+        orc_pm_sweep(s, 1, 1, 1);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* plane <-> depth kernels                                                                     */
+/* host fill main.cpp:1479-1490 + gipuma_get_disp gipuma.cu:731-755 */
+void orc_load_planes(orc_state *s, const float *depth, const float *normal_world) {
+    const orc_camera *cm = &s->cam[0];
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            float n[4];
+            mat3vec(cm->Rorig, normal_world + 3 * p, n);
+            s->c[p] = 1.0f;
+            float disp = cm->f * cm->baseline / depth[p];    /* lines->depth holds f*b/depth (main.cpp:1488) */
+            s->depth[p] = disp;
+            float disp_new = cm->f * cm->baseline / disp;      /* gipuma.cu:751-752 */
+            n[3] = getD(n, x, y, disp_new, cm);
+            memcpy(s->norm4 + 4 * p, n, 16);
+        }
+}
+/* gipuma_compute_disp gipuma.cu:810-844: out4 = (n_world, depth or 0) */
+void orc_compute_disp(const orc_state *s, float *out4) {
+    const orc_camera *cm = &s->cam[0];
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            const float *n = s->norm4 + 4 * p;
+            float o[4];
+            mat3vec(cm->RorigInv, n, o);
+            o[3] = (s->c[p] != ORC_MAXCOST) ? depth_from_plane(cm, n, x, y) : 0.0f;
+            memcpy(out4 + 4 * p, o, 16);
+        }
+}
+/* gipuma_dptow gipuma.cu:1140-1158 */
+void orc_depth_to_plane(orc_state *s) {
+    const orc_camera *cm = &s->cam[0];
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            float disp = cm->f * cm->baseline / s->depth[p];
+            s->norm4[4 * p + 3] = getD(s->norm4 + 4 * p, x, y, disp, cm);
+        }
+}
+/* gipuma_compute_disp_final gipuma.cu:757-808; resize4 [h][w][4], text [h][w]; out4 as compute_disp;
+ * also updates s->norm4 (camera-frame plane after merge/clamp) and s->depth */
+void orc_compute_disp_final(orc_state *s, const float *resize4, const float *text, float *out4) {
+    const orc_camera *cm = &s->cam[0];
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            float n[4];
+            memcpy(n, s->norm4 + 4 * p, 16);
+            float depth_now = depth_from_plane(cm, n, x, y);
+            float disp_now = cm->f * cm->baseline / depth_now;
+            float depth_org = depth_from_plane(cm, resize4 + 4 * p, x, y);
+            float disp_org = cm->f * cm->baseline / depth_org;
+            if ((fabsf(disp_now - disp_org) > 6.0f && text[p] == 1.0f) || text[p] == -1.0f) memcpy(n, resize4 + 4 * p, 16);
+            float d = depth_from_plane(cm, n, x, y);
+            if (d > cm->depthMax) n[3] = getD(n, x, y, cm->depthMax, cm);
+            if (d < cm->depthMin) n[3] = getD(n, x, y, cm->depthMin, cm);
+            s->depth[p] = depth_from_plane(cm, n, x, y);
+            memcpy(s->norm4 + 4 * p, n, 16);
+            float o[4];
+            mat3vec(cm->RorigInv, n, o);
+            o[3] = (s->c[p] != ORC_MAXCOST) ? depth_from_plane(cm, n, x, y) : 0.0f;
+            memcpy(out4 + 4 * p, o, 16);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* TSAR refinement kernels                                                                     */
+/* rlCost gipuma.cu:300-392 */
+static float rl_cost(const orc_state *s, int view, int x, int y, const float *n4) {
+    const float *l = s->img[0], *r = s->img[view];
+    const int w = s->w, h = s->h;
+    float H[9], V[9];
+    homography(&s->cam[0], &s->cam[view], n4, H);
+    float det = H[0] * H[4] * H[8] + H[1] * H[5] * H[6] + H[2] * H[3] * H[7] - H[2] * H[4] * H[6] - H[1] * H[3] * H[8] - H[0] * H[5] * H[7];
+    V[0] = (H[4] * H[8] - H[5] * H[7]) / det;
+    V[1] = -(H[1] * H[8] - H[2] * H[7]) / det;
+    V[2] = (H[1] * H[5] - H[2] * H[4]) / det;
+    V[3] = -(H[3] * H[8] - H[5] * H[6]) / det;
+    V[4] = (H[0] * H[8] - H[2] * H[6]) / det;
+    V[5] = -(H[0] * H[5] - H[2] * H[3]) / det;
+    V[6] = (H[3] * H[7] - H[4] * H[6]) / det;
+    V[7] = -(H[0] * H[7] - H[1] * H[6]) / det;
+    V[8] = (H[0] * H[4] - H[1] * H[3]) / det;
+    float xf = (float)x, yf = (float)y;
+    float Zc = fmaf(H[7], yf, fmaf(H[6], xf, H[8]));
+    float pcx = fmaf(H[1], yf, fmaf(H[0], xf, H[2])) / Zc, pcy = fmaf(H[4], yf, fmaf(H[3], xf, H[5])) / Zc;
+    float cen = bilinear(r, w, h, pcx, pcy);
+    float sum_ref = 0, sum_ref_ref = 0, sum_src = 0, sum_src_src = 0, sum_ref_src = 0, wsum = 0;
+    for (int i = -s->hrad; i < s->hrad + 1; i += 2)
+        for (int j = -s->vrad; j < s->vrad + 1; j += 2) {
+            /* make_int2(pt_c.x + i, pt_c.y + j): float -> int truncation (:355) */
+            float fx_ = fminf(fmaxf(pcx + (float)i, -2.0e9f), 2.0e9f), fy_ = fminf(fmaxf(pcy + (float)j, -2.0e9f), 2.0e9f);
+            int plx = (int)fx_, ply = (int)fy_;
+            float ref_pix = texel(r, w, h, plx, ply);
+            float qx = (float)plx, qy = (float)ply;
+            float Z = fmaf(V[7], qy, fmaf(V[6], qx, V[8]));
+            float X = fmaf(V[1], qy, fmaf(V[0], qx, V[2])), Y = fmaf(V[4], qy, fmaf(V[3], qx, V[5]));
+            float src_pix = bilinear(l, w, h, X / Z, Y / Z);
+            float sd = sqrtf((float)(i * i + j * j));
+            float cd = fabsf(ref_pix - cen);
+            float wt = orc_expf(-sd / 50.0f - cd / 18.0f);
+            float wr = wt * ref_pix, ws = wt * src_pix;
+            sum_ref += wr;
+            sum_ref_ref = fmaf(wr, ref_pix, sum_ref_ref);
+            sum_src += ws;
+            sum_src_src = fmaf(ws, src_pix, sum_src_src);
+            sum_ref_src = fmaf(wr, src_pix, sum_ref_src);
+            wsum += wt;
+        }
+    float inv = 1.0f / wsum;
+    sum_ref *= inv; sum_ref_ref *= inv; sum_src *= inv; sum_src_src *= inv; sum_ref_src *= inv;
+    float var_ref = sum_ref_ref - sum_ref * sum_ref;
+    float var_src = sum_src_src - sum_src * sum_src;
+    if (var_ref < 1e-5f || var_src < 1e-5f) return ORC_MAXCOST;
+    float covar = sum_ref_src - sum_ref * sum_src;
+    return fmaxf(0.0f, fminf(ORC_MAXCOST, 1.0f - covar / sqrtf(var_ref * var_src)));
+}
+/* gipuma_getlrdiff gipuma.cu:1160-1186; pixels whose beview is not a valid source view keep lrdiff */
+void orc_lrdiff(orc_state *s) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            int v = s->beview[p];
+            if (v < 1 || v >= s->n_views) continue;
+            float d = fabsf(s->c[p] - rl_cost(s, v, x, y, s->norm4 + 4 * p));
+            s->lrdiff[p] = d > 1.0f ? 1.0f : d;
+        }
+}
+/* gipuma_getview gipuma.cu:1188-1213 */
+void orc_getview(orc_state *s) {
+    const orc_camera *cm = &s->cam[0];
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            s->confid[p] = ((2.0f - s->c[p]) / 2.0f + (1.0f - s->lrdiff[p])) / 2.0f;
+            float d = depth_from_plane(cm, s->norm4 + 4 * p, x, y);
+            s->depth[p] = cm->f * cm->baseline / d;
+        }
+}
+/* shared by update_scale / update_scale_2: region plane oriented towards the camera */
+static inline void region_plane(const orc_state *s, int region, int x, int y, float *n4) {
+    float vv[3];
+    view_vector(&s->cam[0], x, y, vv);
+    memcpy(n4, s->region_norm4 + 4 * (size_t)region, 16);
+    float dp = n4[0] * vv[0] + n4[1] * vv[1] + n4[2] * vv[2];
+    if (dp > 0.0f) { n4[0] *= -1; n4[1] *= -1; n4[2] *= -1; n4[3] *= -1; }
+}
+/* gipuma_update_scale_2 gipuma.cu:1261-1292 */
+void orc_fake_depth(orc_state *s) {
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            int rg = s->canny[p];
+            if (s->region_text[rg] == -1.0f) {
+                float n4[4];
+                region_plane(s, rg, x, y, n4);
+                s->fakedepth[p] = depth_from_plane(&s->cam[0], n4, x, y);
+            }
+        }
+}
+/* gipuma_update_scale gipuma.cu:1215-1259 */
+void orc_update_scale(orc_state *s) {
+    const orc_camera *cm = &s->cam[0];
+#pragma omp parallel for
+    for (int y = 0; y < s->h; y++)
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            int rg = s->canny[p];
+            if (s->region_text[rg] == -1.0f) {
+                float n4[4];
+                s->c[p] = 0.0f;
+                s->scale[p] = 1.0f;
+                region_plane(s, rg, x, y, n4);
+                memcpy(s->norm4 + 4 * p, n4, 16);
+            }
+            float d = depth_from_plane(cm, s->norm4 + 4 * p, x, y);
+            s->depth[p] = cm->f * cm->baseline / d;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* state plumbing for ctypes                                                                   */
+orc_state *orc_create(int w, int h) {
+    orc_state *s = (orc_state *)calloc(1, sizeof(orc_state));
+    size_t np = (size_t)w * h;
+    s->w = w; s->h = h;
+    s->c = (float *)calloc(np, 4); s->norm4 = (float *)calloc(np, 16); s->ratio = (float *)calloc(np, 4);
+    s->depth = (float *)calloc(np, 4); s->scale = (float *)calloc(np, 4); s->lrdiff = (float *)calloc(np, 4);
+    s->confid = (float *)calloc(np, 4); s->fakedepth = (float *)calloc(np, 4);
+    s->beview = (int32_t *)calloc(np, 4); s->canny = (int32_t *)calloc(np, 4);
+    s->n_best = 1; s->cost_comb = 1; s->hrad = 5; s->vrad = 5;
+    return s;
+}
+void orc_destroy(orc_state *s) {
+    if (!s) return;
+    free(s->c); free(s->norm4); free(s->ratio); free(s->depth); free(s->scale); free(s->lrdiff);
+    free(s->confid); free(s->fakedepth); free(s->beview); free(s->canny);
+    free(s->region_text); free(s->region_norm4); free(s->region_size);
+    free(s);
+}
+void orc_set_image(orc_state *s, int view, const float *img) { s->img[view] = img; } /* borrowed */
+void orc_set_params(orc_state *s, int box_hsize, int box_vsize, int n_best, int cost_comb, uint32_t flags, uint64_t seed) {
+    s->hrad = (box_hsize - 1) / 2; s->vrad = (box_vsize - 1) / 2; /* gipuma.cu:858-859 */
+    s->n_best = n_best; s->cost_comb = cost_comb; s->flags = flags; s->seed = seed;
+}
+void orc_set_subset(orc_state *s, int n, const int32_t *idx) {
+    s->n_sel = n;
+    for (int i = 0; i < n; i++) s->sel[i] = idx[i];
+}
+void orc_set_regions(orc_state *s, const int32_t *labels, int n_regions, const float *text, const float *size) {
+    memcpy(s->canny, labels, (size_t)s->w * s->h * 4);
+    free(s->region_text); free(s->region_norm4); free(s->region_size);
+    s->n_regions = n_regions;
+    s->region_text = (float *)malloc((size_t)n_regions * 4);
+    s->region_size = (float *)calloc((size_t)n_regions, 4);
+    s->region_norm4 = (float *)calloc((size_t)n_regions, 16);
+    memcpy(s->region_text, text, (size_t)n_regions * 4);
+    if (size) memcpy(s->region_size, size, (size_t)n_regions * 4);
+}
+void orc_set_region_planes(orc_state *s, const float *planes) { memcpy(s->region_norm4, planes, (size_t)s->n_regions * 16); }
+float *orc_plane_c(orc_state *s) { return s->c; }
+float *orc_plane_norm4(orc_state *s) { return s->norm4; }
+float *orc_plane_ratio(orc_state *s) { return s->ratio; }
+int32_t *orc_plane_beview(orc_state *s) { return s->beview; }
+float *orc_plane_depth(orc_state *s) { return s->depth; }
+float *orc_plane_scale(orc_state *s) { return s->scale; }
+float *orc_plane_lrdiff(orc_state *s) { return s->lrdiff; }
+float *orc_plane_confid(orc_state *s) { return s->confid; }
+float *orc_plane_fakedepth(orc_state *s) { return s->fakedepth; }
+const orc_camera *orc_camera_ptr(const orc_state *s, int view) { return &s->cam[view]; }
+int orc_camera_sizeof(void) { return (int)sizeof(orc_camera); }
+float orc_min_disp(const orc_state *s) { return s->min_disp; }
+float orc_max_disp(const orc_state *s) { return s->max_disp; }
+void orc_set_launch(orc_state *s, int launch) { s->launch = launch; }

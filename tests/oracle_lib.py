@@ -1,0 +1,281 @@
+"""ctypes binding of the CPU oracle (oracle/libtsar_oracle.so).  Test infrastructure: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libtsar_oracle.so")
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build_oracle(force: bool = False) -> str:
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".c")]
+    stale = (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libtsar_oracle.so"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        for name in ("c", "norm4", "ratio", "depth", "scale", "lrdiff", "confid", "fakedepth"):
+            fn = getattr(L, "orc_plane_" + name)
+            fn.restype = _f32p
+            fn.argtypes = [C.c_void_p]
+        L.orc_plane_beview.restype = _i32p
+        L.orc_plane_beview.argtypes = [C.c_void_p]
+        L.orc_expf.restype = C.c_float
+        L.orc_expf.argtypes = [C.c_float]
+        L.orc_bilinear.restype = C.c_float
+        L.orc_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_pm_cost.restype = C.c_float
+        L.orc_pm_cost.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_pm_cost_multiview.restype = C.c_float
+        L.orc_pm_cost_multiview.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_getD.restype = C.c_float
+        L.orc_getD.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.orc_depth_from_plane.restype = C.c_float
+        L.orc_depth_from_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_min_disp.restype = C.c_float
+        L.orc_max_disp.restype = C.c_float
+        L.orc_min_disp.argtypes = [C.c_void_p]
+        L.orc_max_disp.argtypes = [C.c_void_p]
+        L.orc_camera_ptr.restype = C.c_void_p
+        L.orc_camera_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
+        L.orc_derive_cameras.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.orc_rng4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_iterate", "orc_pm_cost_planes",
+                  "orc_select_candidates", "orc_homography", "orc_view_vector", "orc_load_planes", "orc_compute_disp",
+                  "orc_depth_to_plane", "orc_compute_disp_final", "orc_lrdiff", "orc_getview", "orc_fake_depth",
+                  "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch"):
+            getattr(L, n).restype = None
+        L.orc_refine_steps.restype = C.c_int
+        L.orc_refine_steps.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CameraView(C.Structure):
+    _fields_ = [("K", C.c_float * 9), ("Kinv", C.c_float * 9), ("R", C.c_float * 9), ("t", C.c_float * 3),
+                ("Minv", C.c_float * 9), ("P34", C.c_float * 3), ("C", C.c_float * 3),
+                ("Rorig", C.c_float * 9), ("RorigInv", C.c_float * 9),
+                ("fx", C.c_float), ("fy", C.c_float), ("f", C.c_float), ("alpha", C.c_float),
+                ("baseline", C.c_float), ("depthMin", C.c_float), ("depthMax", C.c_float)]
+
+
+class Oracle:
+    """Host-side mirror of the matcher state used by the parity tests."""
+
+    def __init__(self, images, K, R, t, depth_min, depth_max, box=11, n_best=1, cost_comb=1, flags=0, seed=2024,
+                 cam_scale=1.0, subset=None):
+        L = lib()
+        self.L = L
+        self.images = [np.ascontiguousarray(np.asarray(im, dtype=np.float32)) for im in images]
+        self.h, self.w = self.images[0].shape
+        self.n_views = len(self.images)
+        self.s = C.c_void_p(L.orc_create(self.w, self.h))
+        for v, im in enumerate(self.images):
+            L.orc_set_image(self.s, C.c_int(v), _p(im))
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        R = np.ascontiguousarray(R, dtype=np.float32)
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        L.orc_derive_cameras(self.s, self.n_views, _p(K), _p(R), _p(t), C.c_float(cam_scale), C.c_float(depth_min), C.c_float(depth_max))
+        L.orc_set_params(self.s, box, box, n_best, cost_comb, flags, seed)
+        if subset is None:
+            subset = list(range(1, self.n_views))
+        sub = np.asarray(subset, dtype=np.int32)
+        L.orc_set_subset(self.s, len(sub), _p(sub))
+        self.n_sel = len(sub)
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.s)
+        except Exception:
+            pass
+
+    # ---- raw plane views (numpy arrays aliasing the oracle's memory) ----
+    def _plane(self, name, shape, dtype=np.float32):
+        ptr = getattr(self.L, "orc_plane_" + name)(self.s)
+        return np.ctypeslib.as_array(ptr, shape=shape)
+
+    @property
+    def c(self):
+        return self._plane("c", (self.h, self.w))
+
+    @property
+    def norm4(self):
+        return self._plane("norm4", (self.h, self.w, 4))
+
+    @property
+    def ratio(self):
+        return self._plane("ratio", (self.h, self.w))
+
+    @property
+    def beview(self):
+        return self._plane("beview", (self.h, self.w))
+
+    @property
+    def depth(self):
+        return self._plane("depth", (self.h, self.w))
+
+    @property
+    def scale(self):
+        return self._plane("scale", (self.h, self.w))
+
+    @property
+    def lrdiff(self):
+        return self._plane("lrdiff", (self.h, self.w))
+
+    @property
+    def confid(self):
+        return self._plane("confid", (self.h, self.w))
+
+    @property
+    def fakedepth(self):
+        return self._plane("fakedepth", (self.h, self.w))
+
+    def camera(self, view) -> CameraView:
+        return CameraView.from_address(self.L.orc_camera_ptr(self.s, view))
+
+    @property
+    def min_disp(self):
+        return self.L.orc_min_disp(self.s)
+
+    @property
+    def max_disp(self):
+        return self.L.orc_max_disp(self.s)
+
+    # ---- operators ----
+    def pm_cost(self, view, x, y, n4):
+        n4 = np.ascontiguousarray(n4, dtype=np.float32)
+        return float(self.L.orc_pm_cost(self.s, view, x, y, _p(n4)))
+
+    def pm_cost_multiview(self, x, y, n4):
+        n4 = np.ascontiguousarray(n4, dtype=np.float32)
+        bv = C.c_int(0)
+        rt = C.c_float(0)
+        c = self.L.orc_pm_cost_multiview(self.s, x, y, _p(n4), C.byref(bv), C.byref(rt))
+        return float(c), bv.value, rt.value
+
+    def pm_cost_planes(self, planes):
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        cost = np.empty((self.h, self.w), np.float32)
+        bv = np.empty((self.h, self.w), np.int32)
+        rt = np.empty((self.h, self.w), np.float32)
+        self.L.orc_pm_cost_planes(self.s, _p(planes), _p(cost), _p(bv), _p(rt))
+        return cost, bv, rt
+
+    def homography(self, view, n4):
+        n4 = np.ascontiguousarray(n4, dtype=np.float32)
+        H = np.empty(9, np.float32)
+        self.L.orc_homography(self.s, C.c_int(view), _p(n4), _p(H))
+        return H.reshape(3, 3)
+
+    def getD(self, n, x, y, depth):
+        n = np.ascontiguousarray(n, dtype=np.float32)
+        return float(self.L.orc_getD(self.s, _p(n), x, y, C.c_float(depth)))
+
+    def depth_from_plane(self, n4, x, y):
+        n4 = np.ascontiguousarray(n4, dtype=np.float32)
+        return float(self.L.orc_depth_from_plane(self.s, _p(n4), x, y))
+
+    def view_vector(self, x, y):
+        v = np.empty(3, np.float32)
+        self.L.orc_view_vector(self.s, C.c_int(x), C.c_int(y), _p(v))
+        return v
+
+    def select_candidates(self, c, x, y):
+        c = np.ascontiguousarray(c, dtype=np.float32)
+        out = np.empty(8, np.int32)
+        self.L.orc_select_candidates(self.s, _p(c), C.c_int(x), C.c_int(y), _p(out))
+        return out
+
+    def pm_init(self):
+        self.L.orc_pm_init(self.s)
+
+    def pm_sweep(self, colour, do_prop=1, do_refine=1):
+        self.L.orc_pm_sweep(self.s, C.c_int(colour), C.c_int(do_prop), C.c_int(do_refine))
+
+    def pm_iterate(self, iters):
+        self.L.orc_pm_iterate(self.s, C.c_int(iters))
+
+    def set_launch(self, n):
+        self.L.orc_set_launch(self.s, C.c_int(n))
+
+    def refine_steps(self):
+        return int(self.L.orc_refine_steps(self.s))
+
+    def load_planes(self, depth, normal_world):
+        d = np.ascontiguousarray(depth, np.float32)
+        n = np.ascontiguousarray(normal_world, np.float32)
+        self.L.orc_load_planes(self.s, _p(d), _p(n))
+
+    def compute_disp(self):
+        out = np.empty((self.h, self.w, 4), np.float32)
+        self.L.orc_compute_disp(self.s, _p(out))
+        return out
+
+    def compute_disp_final(self, resize4, text):
+        r = np.ascontiguousarray(resize4, np.float32)
+        tx = np.ascontiguousarray(text, np.float32)
+        out = np.empty((self.h, self.w, 4), np.float32)
+        self.L.orc_compute_disp_final(self.s, _p(r), _p(tx), _p(out))
+        return out
+
+    def depth_to_plane(self):
+        self.L.orc_depth_to_plane(self.s)
+
+    def lrdiff_op(self):
+        self.L.orc_lrdiff(self.s)
+
+    def getview(self):
+        self.L.orc_getview(self.s)
+
+    def set_regions(self, labels, text, size=None):
+        lb = np.ascontiguousarray(labels, np.int32)
+        tx = np.ascontiguousarray(text, np.float32)
+        sz = np.ascontiguousarray(size, np.float32) if size is not None else None
+        self.L.orc_set_regions(self.s, _p(lb), C.c_int(len(tx)), _p(tx), _p(sz) if sz is not None else None)
+        self.n_regions = len(tx)
+
+    def set_region_planes(self, planes):
+        pl = np.ascontiguousarray(planes, np.float32)
+        self.L.orc_set_region_planes(self.s, _p(pl))
+
+    def fake_depth(self):
+        self.L.orc_fake_depth(self.s)
+
+    def update_scale(self):
+        self.L.orc_update_scale(self.s)
+
+
+def rng4(seed, pixel, stream, step):
+    u = np.empty(4, np.float32)
+    lib().orc_rng4(C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(stream), C.c_uint32(step), _p(u))
+    return u
+
+
+def expf(x):
+    return float(lib().orc_expf(C.c_float(x)))
