@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — depthmap Mpixels/s of the PatchMatch matcher (BASELINE.json metric).
+
+One "step" = the whole hot path for one reference view: random init + ITERS red/black iterations
+(propagation + refinement) + plane->depth conversion, at BASELINE.json configs[1]:
+ETH3D full resolution 6048x4032, 10 source views, 8 iterations, --blocksize 11, --n_best 1
+(reference scripts/courtyard.sh:10-15).  Inputs (images, cameras) are resident in HBM before the timed
+region.  N GPUs = N reference views, one per rank (weak scaling), results gathered to rank 0 over RCCL
+inside the timed region (the "gather before fusion" of the north star).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 6048 --height 4032 --views 10 --iters 8]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def alg_bytes_per_pixel_iteration(n_src: int) -> int:
+    """compulsory HBM bytes for one pixel through propagation + refinement once."""
+    return 136 + 16 * (1 + n_src)
+
+
+def cpu_baseline(args):
+    """The CPU oracle (kind "port": the reference has no CPU path) on a bounded sample of the same
+    workload: same view count / window / iterations, smaller image."""
+    import ctypes
+    import oracle_lib as ol
+    from tsar_mvs_amd import synth
+    w, h = args.cpu_width, args.cpu_height
+    sc = synth.make_scene(w, h, args.views, seed=1234, step=args.cam_step)
+    orc = ol.Oracle([im.numpy() for im in sc.images], sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, box=args.box, n_best=args.n_best)
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        cores = int(omp.omp_get_max_threads())
+    except OSError:
+        cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    orc.pm_init()
+    orc.pm_iterate(args.iters)
+    orc.compute_disp()
+    dt = time.perf_counter() - t0
+    return {"value": w * h / dt / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"{w}x{h} synthetic view, {args.views} src views, {args.iters} iters, box {args.box} (CPU oracle, OpenMP), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=6048)
+    ap.add_argument("--height", type=int, default=4032)
+    ap.add_argument("--views", type=int, default=10, help="source views per reference view")
+    ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--box", type=int, default=11)
+    ap.add_argument("--n_best", type=int, default=1)
+    ap.add_argument("--cam-step", type=float, default=0.03, dest="cam_step")
+    ap.add_argument("--cpu-width", type=int, default=960, dest="cpu_width")
+    ap.add_argument("--cpu-height", type=int, default=640, dest="cpu_height")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from tsar_mvs_amd import api, synth
+    from tsar_mvs_amd.driver import gather_results
+
+    # each rank owns one reference view of the scene (its own camera arc position), SURVEY §8(e)
+    sc = synth.make_scene(args.width, args.height, args.views, device=dev, seed=1234, cam_seed=42 + rank, step=args.cam_step)
+    m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024 + rank, device=local_rank)
+    w, h = args.width, args.height
+    out_depth = torch.empty((h, w), dtype=torch.float32, device=dev)
+    out_normal = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+    out_cost = torch.empty((h, w), dtype=torch.float32, device=dev)
+
+    def step():
+        m.pm_init()
+        m.pm_iterate(args.iters)
+        m.compute_disp()
+        m.get_result_device(depth=out_depth, normal=out_normal, cost=out_cost)
+        if dist is not None:
+            gather_results(dist, [out_depth, out_normal, out_cost], dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_timing:
+        m.enable_kernel_timing(True)
+        m.reset_kernel_timing()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    timing = {} if args.no_kernel_timing else m.kernel_timing()
+    # sanity on the product of the timed region (not part of the metric): converged depth vs the analytic scene
+    gt = sc.gt_depth
+    frac_ok = float(((out_depth - gt).abs() / gt < 0.01).float().mean().item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * w * h * args.steps / dt / 1e6
+        line = {
+            "metric": "depthmap Mpixels/sec (ETH3D full-res, 8 iters)", "value": value, "unit": "Mpix/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ETH3D-size view {w}x{h}, 1 ref + {args.views} src views, {args.iters} PatchMatch iters, box {args.box}, n_best {args.n_best}; one ref view per GPU",
+                       "width": w, "height": h, "src_views": args.views, "iters": args.iters, "frac_depth_within_1pct_of_gt": round(frac_ok, 4)},
+        }
+        if "pm_sweep" in timing and timing["pm_sweep"][0] > 0:
+            launches, total_ms = timing["pm_sweep"]
+            avg_ms = total_ms / launches
+            bytes_per_launch = alg_bytes_per_pixel_iteration(args.views) * (w * h / 2.0)   # one launch = one colour = W*H/2 pixel-iterations
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                                "kernel": "pm_sweep_kernel", "avg_launch_ms": avg_ms, "launches": launches,
+                                "algorithmic_bytes_per_launch": bytes_per_launch,
+                                "note": "the kernel is FP32-VALU/gather bound (SURVEY 8d: ~970 flop/B); HBM fraction is reported because the metric asks for it"}
+            line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,11 @@ int tsar_pm_cost_planes(tsar_ctx* ctx, const float* planes, int mem, float* cost
                         int32_t* beview_out, float* ratio_out);
 /* Diagnostics: overwrite / read the raw matcher state: planes [h][w][4] + cost [h][w]. */
 int tsar_set_plane(tsar_ctx* ctx, const float* planes, const float* cost, int mem);
+/* Diagnostics: ONE half-iteration (colour 0 = black: (x+y) even, 1 = red), optionally only its
+ * propagation or only its refinement half (the reference's four kernels gipuma.cu:1096-1138), and
+ * the RNG stream counter (number of half-iterations done so far) that keys the refinement draws. */
+int tsar_pm_sweep(tsar_ctx* ctx, int colour, int do_prop, int do_refine);
+int tsar_set_sweep_counter(tsar_ctx* ctx, int n);
 int tsar_get_plane(tsar_ctx* ctx, float* planes, float* cost, int32_t* beview, float* ratio, int mem);
 
 /* ---- plane <-> depth (reference gipuma.cu:731-844, 1140-1158) ---------------------------- */

@@ -1,0 +1,289 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, libtsar_hip.so) against the CPU oracle on
+the same seeded inputs.
+
+Two arithmetic modes are checked:
+  strict (TSAR_FLAG_STRICT_DIV): every operation is a single IEEE fp32 op in the oracle's order, so the
+      GPU must reproduce the oracle BIT FOR BIT — planes, costs, best views, after whole iterations.
+  fast (default): the per-tap perspective divide uses v_rcp_f32 (1 ulp) instead of two IEEE divisions.
+      Tolerance: |cost_gpu - cost_oracle| <= 2e-3 absolute on the same plane (cost lives in [0, 2]; the
+      fp32 cancellation in var = E[x^2]-E[x]^2 amplifies a 1-ulp change of a tap position), and after
+      one half-iteration from a common state >= 93 % of pixels end on the bit-identical plane (the rest are
+      near-ties flipped by the 2e-3 cost noise); whole runs are compared as distributions.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from tsar_mvs_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+FAST_COST_ATOL = 2e-3
+
+
+def _oracle(scene, **kw):
+    return ol.Oracle([im.cpu().numpy() for im in scene.images], scene.K, scene.R, scene.t, scene.depth_min, scene.depth_max, **kw)
+
+
+def _random_planes(scene, orc, seed):
+    """random valid planes: random depth in range + random normal facing the camera"""
+    rng = np.random.default_rng(seed)
+    h, w = scene.h, scene.w
+    planes = np.empty((h, w, 4), np.float32)
+    for y in range(h):
+        for x in range(w):
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            if n @ orc.view_vector(x, y) > 0:
+                n = -n
+            depth = rng.uniform(scene.depth_min, scene.depth_max)
+            n = n.astype(np.float32)
+            planes[y, x, :3] = n
+            planes[y, x, 3] = orc.getD(n, x, y, depth)
+    return planes
+
+
+@pytest.mark.parametrize("box,n_best,comb", [(11, 1, 1), (11, 2, 1), (7, 3, 1), (11, 1, 0), (19, 2, 1)])
+def test_cost_planes_strict_bit_exact(small_scene, box, n_best, comb):
+    sc = small_scene
+    orc = _oracle(sc, box=box, n_best=n_best, cost_comb=comb)
+    m = api.matcher_from_scene(sc, box=box, n_best=n_best, cost_comb=comb, flags=api.FLAG_STRICT_DIV)
+    for planes in (synth.gt_planes(sc).numpy(), _random_planes(sc, orc, 3)):
+        c_ref, bv_ref, rt_ref = orc.pm_cost_planes(planes)
+        c, bv, rt = m.pm_cost_planes(planes)
+        assert np.array_equal(c, c_ref)
+        assert np.array_equal(bv, bv_ref)
+        assert np.array_equal(rt.view(np.uint32), rt_ref.view(np.uint32))
+    m.close()
+
+
+def test_cost_planes_fast_tolerance(small_scene):
+    sc = small_scene
+    orc = _oracle(sc)
+    m = api.matcher_from_scene(sc)
+    for planes in (synth.gt_planes(sc).numpy(), _random_planes(sc, orc, 5)):
+        c_ref, bv_ref, _ = orc.pm_cost_planes(planes)
+        c, bv, _ = m.pm_cost_planes(planes)
+        assert np.max(np.abs(c - c_ref)) <= FAST_COST_ATOL
+        assert np.mean(bv == bv_ref) > 0.995
+    m.close()
+
+
+def test_float_image_path_matches_quad_path(small_scene):
+    """non-integral images take the 4-load float path; on integral images both paths must agree exactly"""
+    sc = small_scene
+    orc = _oracle(sc)
+    planes = _random_planes(sc, orc, 9)
+    m = api.matcher_from_scene(sc, flags=api.FLAG_STRICT_DIV)
+    c_quad, _, _ = m.pm_cost_planes(planes)
+    m.close()
+    # perturb one pixel of a source image by 0.5 -> library must fall back to the float path
+    imgs = [im.clone() for im in sc.images]
+    imgs[1][0, 0] += 0.5
+    m2 = api.Matcher()
+    m2.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max,
+                                     flags=api.FLAG_STRICT_DIV, seed=2024))
+    m2.set_views(imgs, sc.K, sc.R, sc.t)
+    c_f, _, _ = m2.pm_cost_planes(planes)
+    m2.close()
+    orc2 = ol.Oracle([im.numpy() for im in imgs], sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max)
+    c_ref, _, _ = orc2.pm_cost_planes(planes)
+    assert np.array_equal(c_f, c_ref)
+    # only windows that can touch source pixel (0,0) may differ between the two inputs
+    assert np.mean(c_f != c_quad) < 0.2
+
+
+def test_init_strict_bit_exact(small_scene):
+    sc = small_scene
+    orc = _oracle(sc, seed=77)
+    orc.pm_init()
+    m = api.matcher_from_scene(sc, seed=77, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    planes, cost, _, _ = m.get_plane()
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(cost, orc.c)
+    m.close()
+
+
+@pytest.mark.parametrize("flags", [0, api.FLAG_FIX_DOWN_FAR_SEED | api.FLAG_FIX_RIGHT_FAR_CMP])
+def test_iterations_strict_bit_exact(small_scene, flags):
+    """two full red/black iterations: propagation (8 arms, snapshot reads) + refinement (Philox draws)"""
+    sc = small_scene
+    orc = _oracle(sc, seed=5, flags=flags)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    m = api.matcher_from_scene(sc, seed=5, flags=flags | api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(2)
+    planes, cost, bv, rt = m.get_plane()
+    assert np.array_equal(cost, orc.c)
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(bv, orc.beview)
+    assert np.array_equal(rt.view(np.uint32), orc.ratio.view(np.uint32))
+    m.close()
+
+
+def test_half_sweeps_strict_bit_exact(small_scene):
+    """the four reference kernels separately: black prop, black refine, red prop, red refine"""
+    sc = small_scene
+    orc = _oracle(sc, seed=9)
+    orc.pm_init()
+    m = api.matcher_from_scene(sc, seed=9, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    for colour, prop, refine in ((0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1)):
+        orc.pm_sweep(colour, prop, refine)
+        m.pm_sweep(colour, bool(prop), bool(refine))
+        planes, cost, _, _ = m.get_plane()
+        assert np.array_equal(cost, orc.c), (colour, prop, refine)
+        assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32)), (colour, prop, refine)
+    m.close()
+
+
+def test_one_sweep_fast_agreement(mid_scene):
+    """from the SAME state, one fast-mode half-iteration takes the same decisions as the oracle except
+    where two hypotheses score within the fast-mode cost tolerance"""
+    sc = mid_scene
+    orc = _oracle(sc, seed=3)
+    orc.pm_init()
+    orc.pm_iterate(1)
+    state_n, state_c = orc.norm4.copy(), orc.c.copy()
+    m = api.matcher_from_scene(sc, seed=3)
+    m.set_plane(state_n, state_c)
+    m.set_sweep_counter(2)
+    orc.pm_sweep(0)
+    m.pm_sweep(0)
+    planes, cost, _, _ = m.get_plane()
+    same = np.all(planes.view(np.uint32) == orc.norm4.view(np.uint32), axis=-1)
+    assert same.mean() >= 0.93, same.mean()
+    assert np.max(np.abs(cost - orc.c)[same]) <= FAST_COST_ATOL
+    # where the decision differs the accepted costs are still within the tolerance band of each other
+    assert np.percentile(np.abs(cost - orc.c)[~same], 95) <= 0.05 if (~same).any() else True
+    m.close()
+
+
+def test_iterations_fast_statistics(mid_scene):
+    """whole runs: greedy accepts make trajectories diverge after a flipped decision, so full fast-mode
+    runs are compared with the oracle as distributions: mean cost and the fraction of
+    pixels converged to the analytic ground truth agree to within 1.5 points"""
+    sc = mid_scene
+    gt = sc.gt_depth.numpy()
+    orc = _oracle(sc, seed=3)
+    orc.pm_init()
+    orc.pm_iterate(3)
+    d_ref = orc.compute_disp()[..., 3]
+    m = api.matcher_from_scene(sc, seed=3)
+    m.pm_init()
+    m.pm_iterate(3)
+    m.compute_disp()
+    res = m.get_result()
+    d = res["depth"]
+    conv_ref = (np.abs(d_ref - gt) / gt < 0.01).mean()
+    conv = (np.abs(d - gt) / gt < 0.01).mean()
+    assert abs(conv - conv_ref) < 0.015, (conv, conv_ref)
+    assert abs(float(res["cost"].mean()) - float(orc.c.mean())) < 2e-3
+    m.close()
+
+
+def test_convergence_to_ground_truth(mid_scene):
+    """property test at a size the oracle is not needed for: depth converges to the analytic scene"""
+    sc = mid_scene
+    m = api.matcher_from_scene(sc, seed=1)
+    m.pm_init()
+    m.pm_iterate(4)
+    m.compute_disp()
+    d = m.get_result(("depth",))["depth"]
+    gt = sc.gt_depth.numpy()
+    good = np.abs(d - gt) / gt < 0.02
+    assert good.mean() > 0.80, good.mean()
+    m.close()
+
+
+def test_plane_depth_kernels_bit_exact(small_scene):
+    sc = small_scene
+    orc = _oracle(sc)
+    gt_d = sc.gt_depth.numpy()
+    n_cam = sc.gt_normal.numpy()
+    Rt = sc.R[0].T
+    n_world = np.ascontiguousarray((n_cam @ Rt.T).astype(np.float32))   # n_w = R^T n_c
+    orc.load_planes(gt_d, n_world)
+    m = api.matcher_from_scene(sc)
+    m.load_planes(gt_d, n_world)
+    planes, cost, _, _ = m.get_plane()
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(cost, orc.c)
+    ref = orc.compute_disp()
+    m.compute_disp()
+    res = m.get_result()
+    assert np.array_equal(res["depth"], ref[..., 3])
+    assert np.array_equal(res["normal"], ref[..., :3])
+    # the round trip reproduces the loaded depth / normals to fp32 accuracy
+    assert np.allclose(res["depth"], gt_d, rtol=2e-5)
+    assert np.allclose(res["normal"], n_world, atol=2e-6)
+    # getview + depth_to_plane
+    orc.getview()
+    m.getview()
+    orc.depth_to_plane()
+    m.depth_to_plane()
+    planes2, _, _, _ = m.get_plane()
+    assert np.array_equal(planes2.view(np.uint32), orc.norm4.view(np.uint32))
+    m.close()
+
+
+def test_textureless_fill_bit_exact(small_scene):
+    sc = small_scene
+    h, w = sc.h, sc.w
+    orc = _oracle(sc, seed=4)
+    orc.pm_init()
+    m = api.matcher_from_scene(sc, seed=4, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    labels = np.zeros((h, w), np.int32)
+    labels[:, w // 3: 2 * w // 3] = 1
+    labels[h // 2:, 2 * w // 3:] = 2
+    text = np.array([1.0, -1.0, -1.0], np.float32)
+    planes = np.array([[0.0, 0.0, 1.0, -5.0], [0.1, -0.2, -0.97, 6.0], [0, 0, 0, 0]], np.float32)
+    planes[1, :3] /= np.linalg.norm(planes[1, :3])
+    planes[2] = planes[1] * np.array([1, 1, 1, 1.1], np.float32)
+    for o in (orc, m):
+        o.set_regions(labels, text)
+        o.set_region_planes(planes)
+    orc.fake_depth()
+    fd = m.fake_depth()
+    msk = labels > 0
+    assert np.array_equal(fd[msk], orc.fakedepth[msk])
+    orc.update_scale()
+    ref = orc.compute_disp()
+    m.fill_textureless()
+    res = m.get_result()
+    assert np.array_equal(res["depth"], ref[..., 3])
+    assert np.array_equal(res["normal"], ref[..., :3])
+    assert np.array_equal(res["cost"], orc.c)
+    m.close()
+
+
+def test_lrdiff_confidence(small_scene):
+    sc = small_scene
+    orc = _oracle(sc, seed=6)
+    orc.pm_init()
+    orc.pm_iterate(1)
+    orc.lrdiff_op()
+    orc.getview()
+    m = api.matcher_from_scene(sc, seed=6, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(1)
+    m.lrdiff()
+    m.getview()
+    m.compute_disp()
+    res = m.get_result()
+    assert np.array_equal(res["confid"], orc.confid)
+    m.close()
+
+
+def test_error_codes():
+    m = api.Matcher()
+    with pytest.raises(api.TsarError) as e:
+        m.pm_init()
+    assert e.value.code == api.TSAR_ERR_STATE
+    with pytest.raises(api.TsarError) as e:
+        m.set_params(api.default_params(depth_min=5.0, depth_max=1.0))
+    assert e.value.code == api.TSAR_ERR_INVALID
+    m.close()

@@ -1,0 +1,358 @@
+"""ctypes binding of libtsar_hip.so (include/tsar.h) and a thin `Matcher` object mirroring the reference's
+operator sequence (`firstcuda` / `sliccuda` / `fakecuda` / `fillcuda`, reference gipuma.h:2-6, called from
+runGipuma, reference main.cpp:1493-1783).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the calls raise.
+Buffers may be numpy arrays (host) or torch CUDA tensors (device, zero-copy via data_ptr()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsar_hip.so")
+
+TSAR_OK = 0
+TSAR_ERR_INVALID, TSAR_ERR_HIP, TSAR_ERR_STATE, TSAR_ERR_NOMEM = -1, -2, -3, -4
+MEM_HOST, MEM_DEVICE = 0, 1
+COMB_ALL, COMB_BEST_N = 0, 1
+FLAG_FIX_DOWN_FAR_SEED, FLAG_FIX_RIGHT_FAR_CMP, FLAG_STRICT_DIV = 1, 2, 4
+MAXCOST = 2.0
+MAX_VIEWS = 64
+
+
+class TsarError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"tsar error {code}: {msg}")
+        self.code = code
+
+
+class Camera(C.Structure):
+    _fields_ = [("K", C.c_float * 9), ("R", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("box_hsize", C.c_int32), ("box_vsize", C.c_int32), ("n_best", C.c_int32), ("cost_comb", C.c_int32),
+                ("depth_min", C.c_float), ("depth_max", C.c_float), ("cam_scale", C.c_float), ("flags", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class SlicSettings(C.Structure):
+    _fields_ = [("spixel_size", C.c_int32), ("no_iters", C.c_int32), ("coh_weight", C.c_float),
+                ("do_enforce_connectivity", C.c_int32), ("color_space", C.c_int32)]
+
+
+class KernelTiming(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
+
+
+# every symbol include/tsar.h declares (tests check that the library exports exactly these)
+ABI_SYMBOLS = [
+    "tsar_create", "tsar_destroy", "tsar_last_error", "tsar_version", "tsar_get_stream", "tsar_synchronize",
+    "tsar_default_params", "tsar_set_params", "tsar_set_views", "tsar_set_view_subset",
+    "tsar_pm_init", "tsar_pm_iterate", "tsar_pm_sweep", "tsar_set_sweep_counter", "tsar_pm_cost_planes", "tsar_set_plane", "tsar_get_plane",
+    "tsar_load_planes", "tsar_compute_disp", "tsar_compute_disp_final", "tsar_depth_to_plane", "tsar_get_result",
+    "tsar_set_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_ransac_regions",
+    "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
+    "tsar_default_slic_settings", "tsar_slic",
+    "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
+]
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load libtsar_hip.so; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `make -C tsar-mvs_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.tsar_last_error.restype = C.c_char_p
+    L.tsar_last_error.argtypes = [C.c_void_p]
+    L.tsar_version.restype = C.c_char_p
+    L.tsar_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.tsar_destroy.argtypes = [C.c_void_p]
+    L.tsar_default_params.restype = None
+    L.tsar_default_params.argtypes = [C.POINTER(Params)]
+    L.tsar_default_slic_settings.restype = None
+    L.tsar_default_slic_settings.argtypes = [C.POINTER(SlicSettings)]
+    L.tsar_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+    L.tsar_set_views.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera)]
+    L.tsar_set_view_subset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.tsar_pm_init.argtypes = [C.c_void_p]
+    L.tsar_pm_iterate.argtypes = [C.c_void_p, C.c_int]
+    L.tsar_pm_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.tsar_set_sweep_counter.argtypes = [C.c_void_p, C.c_int]
+    L.tsar_pm_cost_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tsar_set_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_get_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_load_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_compute_disp.argtypes = [C.c_void_p]
+    L.tsar_compute_disp_final.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_depth_to_plane.argtypes = [C.c_void_p]
+    L.tsar_get_result.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_set_reliable_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_lrdiff.argtypes = [C.c_void_p]
+    L.tsar_getview.argtypes = [C.c_void_p]
+    L.tsar_wmf.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.tsar_set_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_ransac_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tsar_set_region_planes.argtypes = [C.c_void_p, C.c_void_p]
+    L.tsar_fake_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_fill_textureless.argtypes = [C.c_void_p]
+    L.tsar_slic.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(SlicSettings), C.c_void_p, C.c_int]
+    L.tsar_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.tsar_synchronize.argtypes = [C.c_void_p]
+    L.tsar_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    L.tsar_reset_kernel_timing.argtypes = [C.c_void_p]
+    L.tsar_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming), C.c_int, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load_library().tsar_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    """(pointer, mem kind) of a numpy array or torch tensor; None -> (NULL, host)."""
+    if a is None:
+        return None, MEM_HOST
+    if _is_torch(a):
+        assert a.is_contiguous(), "tensor must be contiguous"
+        return C.c_void_p(a.data_ptr()), (MEM_DEVICE if a.is_cuda else MEM_HOST)
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p), MEM_HOST
+
+
+class Matcher:
+    """One context = one GPU.  Mirrors the order in which runGipuma drives the GPU operators."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self._ctx = C.c_void_p()
+        rc = self.L.tsar_create(device, C.byref(self._ctx))
+        if rc != TSAR_OK:
+            raise TsarError(rc, "tsar_create failed (is a HIP device visible?)")
+        self.w = self.h = self.n_views = 0
+        self._keep = []
+
+    def close(self):
+        if self._ctx:
+            self.L.tsar_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != TSAR_OK:
+            raise TsarError(rc, self.L.tsar_last_error(self._ctx).decode())
+
+    # ---- inputs ----
+    def set_params(self, params: Params):
+        self._chk(self.L.tsar_set_params(self._ctx, C.byref(params)))
+        self.params = params
+
+    def set_views(self, images, K, R, t):
+        """images: list of [h, w] float32 arrays/tensors (view 0 = reference); K, R, t: per-view
+        intrinsics and world->camera extrinsics as in cams/%08d_cam.txt."""
+        n = len(images)
+        first = images[0]
+        h, w = int(first.shape[0]), int(first.shape[1])
+        ptrs = (C.c_void_p * n)()
+        kinds = set()
+        for i, im in enumerate(images):
+            assert tuple(im.shape) == (h, w)
+            if not _is_torch(im):
+                im = np.ascontiguousarray(im, dtype=np.float32)
+                self._keep.append(im)
+            p, kind = _ptr(im)
+            ptrs[i] = p
+            kinds.add(kind)
+        assert len(kinds) == 1, "all images must live in the same memory space"
+        cams = (Camera * n)()
+        K = np.asarray(K, np.float32).reshape(n, 9)
+        R = np.asarray(R, np.float32).reshape(n, 9)
+        t = np.asarray(t, np.float32).reshape(n, 3)
+        for i in range(n):
+            cams[i].K[:] = K[i].tolist()
+            cams[i].R[:] = R[i].tolist()
+            cams[i].t[:] = t[i].tolist()
+        self._chk(self.L.tsar_set_views(self._ctx, n, w, h, ptrs, kinds.pop(), cams))
+        self._keep.clear()
+        self.w, self.h, self.n_views = w, h, n
+
+    def set_view_subset(self, idx):
+        a = np.ascontiguousarray(idx, np.int32)
+        self._chk(self.L.tsar_set_view_subset(self._ctx, len(a), a.ctypes.data_as(C.c_void_p)))
+
+    # ---- PatchMatch ----
+    def pm_init(self):
+        self._chk(self.L.tsar_pm_init(self._ctx))
+
+    def pm_iterate(self, iters: int):
+        self._chk(self.L.tsar_pm_iterate(self._ctx, iters))
+
+    def pm_sweep(self, colour: int, do_prop: bool = True, do_refine: bool = True):
+        self._chk(self.L.tsar_pm_sweep(self._ctx, colour, int(do_prop), int(do_refine)))
+
+    def set_sweep_counter(self, n: int):
+        self._chk(self.L.tsar_set_sweep_counter(self._ctx, n))
+
+    def pm_cost_planes(self, planes):
+        planes = np.ascontiguousarray(planes, np.float32)
+        cost = np.empty((self.h, self.w), np.float32)
+        bv = np.empty((self.h, self.w), np.int32)
+        rt = np.empty((self.h, self.w), np.float32)
+        self._chk(self.L.tsar_pm_cost_planes(self._ctx, _ptr(planes)[0], MEM_HOST, _ptr(cost)[0], _ptr(bv)[0], _ptr(rt)[0]))
+        return cost, bv, rt
+
+    def set_plane(self, planes, cost):
+        planes = np.ascontiguousarray(planes, np.float32)
+        cost = np.ascontiguousarray(cost, np.float32)
+        self._chk(self.L.tsar_set_plane(self._ctx, _ptr(planes)[0], _ptr(cost)[0], MEM_HOST))
+
+    def get_plane(self):
+        planes = np.empty((self.h, self.w, 4), np.float32)
+        cost = np.empty((self.h, self.w), np.float32)
+        bv = np.empty((self.h, self.w), np.int32)
+        rt = np.empty((self.h, self.w), np.float32)
+        self._chk(self.L.tsar_get_plane(self._ctx, _ptr(planes)[0], _ptr(cost)[0], _ptr(bv)[0], _ptr(rt)[0], MEM_HOST))
+        return planes, cost, bv, rt
+
+    # ---- plane <-> depth ----
+    def load_planes(self, depth, normal_world):
+        d, kd = _ptr(depth if _is_torch(depth) else np.ascontiguousarray(depth, np.float32))
+        depth_keep = depth if _is_torch(depth) else np.ascontiguousarray(depth, np.float32)
+        normal_keep = normal_world if _is_torch(normal_world) else np.ascontiguousarray(normal_world, np.float32)
+        d, kd = _ptr(depth_keep)
+        n, kn = _ptr(normal_keep)
+        assert kd == kn
+        self._chk(self.L.tsar_load_planes(self._ctx, d, n, kd))
+
+    def compute_disp(self):
+        self._chk(self.L.tsar_compute_disp(self._ctx))
+
+    def compute_disp_final(self, resize_planes, text):
+        r = np.ascontiguousarray(resize_planes, np.float32)
+        t = np.ascontiguousarray(text, np.float32)
+        self._chk(self.L.tsar_compute_disp_final(self._ctx, _ptr(r)[0], _ptr(t)[0], MEM_HOST))
+
+    def depth_to_plane(self):
+        self._chk(self.L.tsar_depth_to_plane(self._ctx))
+
+    def get_result(self, want=("depth", "normal", "cost", "confid")):
+        out = {}
+        depth = np.empty((self.h, self.w), np.float32) if "depth" in want else None
+        normal = np.empty((self.h, self.w, 3), np.float32) if "normal" in want else None
+        cost = np.empty((self.h, self.w), np.float32) if "cost" in want else None
+        confid = np.empty((self.h, self.w), np.float32) if "confid" in want else None
+        self._chk(self.L.tsar_get_result(self._ctx, _ptr(depth)[0], _ptr(normal)[0], _ptr(cost)[0], _ptr(confid)[0], MEM_HOST))
+        for k, v in (("depth", depth), ("normal", normal), ("cost", cost), ("confid", confid)):
+            if v is not None:
+                out[k] = v
+        return out
+
+    def get_result_device(self, depth=None, normal=None, cost=None, confid=None):
+        """Write results into caller-provided torch CUDA tensors."""
+        self._chk(self.L.tsar_get_result(self._ctx, _ptr(depth)[0], _ptr(normal)[0], _ptr(cost)[0], _ptr(confid)[0], MEM_DEVICE))
+
+    # ---- TSAR refinement ----
+    def set_reliable_mask(self, scale):
+        s = np.ascontiguousarray(scale, np.float32)
+        self._chk(self.L.tsar_set_reliable_mask(self._ctx, _ptr(s)[0], MEM_HOST))
+
+    def lrdiff(self):
+        self._chk(self.L.tsar_lrdiff(self._ctx))
+
+    def getview(self):
+        self._chk(self.L.tsar_getview(self._ctx))
+
+    def wmf(self, iters: int, final_pass: bool):
+        self._chk(self.L.tsar_wmf(self._ctx, iters, int(final_pass)))
+
+    def set_regions(self, labels, region_text, region_size=None):
+        lb = np.ascontiguousarray(labels, np.int32)
+        tx = np.ascontiguousarray(region_text, np.float32)
+        sz = np.ascontiguousarray(region_size, np.float32) if region_size is not None else None
+        self._chk(self.L.tsar_set_regions(self._ctx, _ptr(lb)[0], len(tx), _ptr(tx)[0], _ptr(sz)[0], MEM_HOST))
+        self.n_regions = len(tx)
+
+    def ransac_regions(self):
+        planes = np.empty((self.n_regions, 4), np.float32)
+        ratio = np.empty((self.n_regions,), np.float32)
+        self._chk(self.L.tsar_ransac_regions(self._ctx, _ptr(planes)[0], _ptr(ratio)[0]))
+        return planes, ratio
+
+    def set_region_planes(self, planes):
+        pl = np.ascontiguousarray(planes, np.float32)
+        self._chk(self.L.tsar_set_region_planes(self._ctx, _ptr(pl)[0]))
+
+    def fake_depth(self):
+        out = np.empty((self.h, self.w), np.float32)
+        self._chk(self.L.tsar_fake_depth(self._ctx, _ptr(out)[0], MEM_HOST))
+        return out
+
+    def fill_textureless(self):
+        self._chk(self.L.tsar_fill_textureless(self._ctx))
+
+    def slic(self, bgra, settings: SlicSettings | None = None):
+        img = np.ascontiguousarray(bgra, np.uint8)
+        h, w = img.shape[:2]
+        if settings is None:
+            settings = SlicSettings()
+            self.L.tsar_default_slic_settings(C.byref(settings))
+        labels = np.empty((h, w), np.int32)
+        self._chk(self.L.tsar_slic(self._ctx, _ptr(img)[0], w, h, C.byref(settings), _ptr(labels)[0], MEM_HOST))
+        return labels
+
+    # ---- measurement ----
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        self._chk(self.L.tsar_get_stream(self._ctx, C.byref(s)))
+        return s.value or 0
+
+    def synchronize(self):
+        self._chk(self.L.tsar_synchronize(self._ctx))
+
+    def enable_kernel_timing(self, on: bool = True):
+        self._chk(self.L.tsar_enable_kernel_timing(self._ctx, int(on)))
+
+    def reset_kernel_timing(self):
+        self._chk(self.L.tsar_reset_kernel_timing(self._ctx))
+
+    def kernel_timing(self):
+        buf = (KernelTiming * 32)()
+        n = C.c_int(0)
+        self._chk(self.L.tsar_get_kernel_timing(self._ctx, buf, 32, C.byref(n)))
+        return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(min(n.value, 32))}
+
+
+def matcher_from_scene(scene, box=11, n_best=1, cost_comb=COMB_BEST_N, flags=0, seed=2024, device=0, subset=None) -> Matcher:
+    """Convenience used by tests/bench: a Matcher loaded with a tsar_mvs_amd.synth.Scene."""
+    m = Matcher(device)
+    m.set_params(default_params(box_hsize=box, box_vsize=box, n_best=n_best, cost_comb=cost_comb, depth_min=scene.depth_min,
+                                depth_max=scene.depth_max, flags=flags, seed=seed))
+    m.set_views(scene.images, scene.K, scene.R, scene.t)
+    if subset is not None:
+        m.set_view_subset(subset)
+    return m

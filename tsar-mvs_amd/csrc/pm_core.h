@@ -1,0 +1,196 @@
+// pm_core.h — the matching cost and the per-pixel PatchMatch step, shared by the init / sweep /
+// cost-evaluation kernels (pm_init.hip, pm_sweep.hip, pm_cost.hip).
+//
+// Mapping (MI355X-first): one thread owns one pixel and walks its hypotheses; a
+// 256-thread workgroup owns a 32-wide pixel region.  Per workgroup, once per launch:
+//   - the reference-image window (region + halo) is staged in LDS (clamp addressing baked in),
+//   - each thread hoists everything that depends only on its reference pixel out of the
+//     hypothesis x view loop: the S bilateral weights (kept in LDS, [tap][thread] so a wave reads
+//     consecutive banks), sum(w), sum(w r), sum(w r^2) and the reference variance.  The reference
+//     recomputes these S exp() and 3 sums for every one of ~14 hypotheses x N views
+//     (gipuma.cu:259-277); the values are identical, only the work is hoisted.
+//   - pixels whose reference window has no texture (var_ref < 1e-5) can never change (every
+//     hypothesis scores MAXCOST, gipuma.cu:289-291) and stop there.
+// Source taps: the homography-warped position is bilinearly sampled in software (no texture unit on
+// gfx950).  For 8-bit imagery each view is pre-packed into 2x2 texel quads (tex_kernels.hip), so a
+// tap is ONE 4-byte gather instead of four.
+#pragma once
+#include "tsar_device_math.h"
+
+#define PM_BLOCK 256
+#define PM_RW 32  // region width in pixels (all kernels)
+
+template <bool QUAD>
+DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u, float v) {
+    // tex2D(tex, u + .5, v + .5), linear filter, clamp addressing (main.cpp:1215-1219).
+    u = fminf(fmaxf(u, -1.0f), (float)w);
+    v = fminf(fmaxf(v, -1.0f), (float)h);
+    const float fu = floorf(u), fv = floorf(v);
+    const float ax = u - fu, ay = v - fv;
+    const int iu = (int)fu, iv = (int)fv;
+    float t00, t10, t01, t11;
+    if (QUAD) {
+        const uint32_t q = vw.quad[(uint32_t)(__mul24(iv + 1, qpitch) + iu + 1)];
+        t00 = (float)(q & 0xffu);
+        t10 = (float)((q >> 8) & 0xffu);
+        t01 = (float)((q >> 16) & 0xffu);
+        t11 = (float)(q >> 24);
+    } else {
+        const int x0 = min(max(iu, 0), w - 1), x1 = min(max(iu + 1, 0), w - 1);
+        const int y0 = min(max(iv, 0), h - 1), y1 = min(max(iv + 1, 0), h - 1);
+        const float* r0 = vw.img + (size_t)y0 * w;
+        const float* r1 = vw.img + (size_t)y1 * w;
+        t00 = r0[x0]; t10 = r0[x1]; t01 = r1[x0]; t11 = r1[x1];
+    }
+    const float top = fma_(ax, t10 - t00, t00);
+    const float bot = fma_(ax, t11 - t01, t01);
+    return fma_(ay, bot - top, top);
+}
+
+// Per-pixel quantities that do not depend on the hypothesis.
+struct PixelRef {
+    float inv_wsum;   // 1 / sum(w)
+    float mean_ref;   // sum(w r) / sum(w)
+    float var_ref;    // E[r^2] - E[r]^2
+    bool textured;    // var_ref >= kMinVar
+};
+
+// Stage the reference window of this workgroup's region in LDS.  tile is (RW + 2hr) x (RH + 2vr).
+template <int RH>
+DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, float* tile, int x0, int y0, int hr, int vr) {
+    const int tw = PM_RW + 2 * hr, th = RH + 2 * vr;
+    const float* __restrict__ img = sc->view[0].img;
+    const int w = sc->w, h = sc->h;
+    for (int k = threadIdx.x; k < tw * th; k += PM_BLOCK) {
+        const int ty = k / tw, tx = k - ty * tw;
+        const int gx = min(max(x0 + tx - hr, 0), w - 1), gy = min(max(y0 + ty - vr, 0), h - 1);
+        tile[k] = img[(size_t)gy * w + gx];
+    }
+}
+
+// Bilateral weights + reference moments (gipuma.cu:247-277, the parts that depend on the reference
+// image only).  own = index of this thread's pixel in the tile, wts = LDS weight column of this thread.
+template <int HR>
+DEVFN PixelRef hoist_reference(const float* tile, int tw, int own, float* wts, int hr_rt, int vr_rt) {
+    const int hr = HR > 0 ? HR : hr_rt, vr = HR > 0 ? HR : vr_rt;
+    const float cen = tile[own];
+    float sum_ref = 0.f, sum_ref_ref = 0.f, wsum = 0.f;
+    int tap = 0;
+#pragma unroll
+    for (int i = -hr; i <= hr; i += 2) {
+#pragma unroll
+        for (int j = -vr; j <= vr; j += 2) {
+            const float r = tile[own + j * tw + i];
+            const float sd = sqrtf((float)(i * i + j * j));
+            const float cd = fabsf(r - cen);
+            const float wt = tsar_expf(-sd / 50.0f - cd / 18.0f);   // sigma_spatial 5, sigma_color 3 (gipuma.cu:248-249,268)
+            wts[tap * PM_BLOCK] = wt;
+            const float wr = wt * r;
+            sum_ref += wr;
+            sum_ref_ref = fma_(wr, r, sum_ref_ref);
+            wsum += wt;
+            ++tap;
+        }
+    }
+    PixelRef pr;
+    pr.inv_wsum = 1.0f / wsum;
+    sum_ref *= pr.inv_wsum;
+    sum_ref_ref *= pr.inv_wsum;
+    pr.mean_ref = sum_ref;
+    pr.var_ref = sum_ref_ref - sum_ref * sum_ref;
+    pr.textured = !(pr.var_ref < 1e-5f);
+    return pr;
+}
+
+// pmCost gipuma.cu:229-298 for one source view, given the hoisted reference terms.
+template <int HR, bool STRICT, bool QUAD>
+DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const float* tile, int tw, int own, const float* wts,
+                      const PixelRef& pr, int x, int y, const float4& n4) {
+    const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
+    const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
+    float H[9];
+    plane_homography(sc->ref, vw, n4, H);
+    float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
+    int tap = 0;
+#pragma unroll
+    for (int i = -hr; i <= hr; i += 2) {
+        const float xi = (float)(x + i);
+        const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
+#pragma unroll
+        for (int j = -vr; j <= vr; j += 2) {
+            const float yj = (float)(y + j);
+            const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
+            float u, v;
+            if (STRICT) {
+                u = X / Z;
+                v = Y / Z;
+            } else {
+                const float rz = __builtin_amdgcn_rcpf(Z);
+                u = X * rz;
+                v = Y * rz;
+            }
+            const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
+            const float r = tile[own + j * tw + i];
+            const float wt = wts[tap * PM_BLOCK];
+            const float wr = wt * r, ws = wt * s;
+            sum_src += ws;
+            sum_src_src = fma_(ws, s, sum_src_src);
+            sum_ref_src = fma_(wr, s, sum_ref_src);
+            ++tap;
+        }
+    }
+    sum_src *= pr.inv_wsum;
+    sum_src_src *= pr.inv_wsum;
+    sum_ref_src *= pr.inv_wsum;
+    const float var_src = sum_src_src - sum_src * sum_src;
+    if (var_src < 1e-5f) return TSAR_MAXCOST;
+    const float covar = sum_ref_src - pr.mean_ref * sum_src;
+    const float vrs = sqrtf(pr.var_ref * var_src);
+    return fmaxf(0.0f, fminf(TSAR_MAXCOST, 1.0f - covar / vrs));
+}
+
+// pmCostMultiview_cu gipuma.cu:455-518: best-N combination over the selected views.  The NB
+// smallest costs are kept sorted in registers (sort_small :425-434 sorts all of them).
+template <int NB, int HR, bool STRICT, bool QUAD>
+DEVFN float multiview_cost(const DevScene* __restrict__ sc, const float* tile, int tw, int own, const float* wts, const PixelRef& pr,
+                           int x, int y, const float4& n4, int& beview, float& ratio) {
+    float best[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) best[k] = __builtin_inff();
+    const int num = sc->n_sel;
+    int valid = 0, bv = -1;
+    float cmin = __builtin_inff();
+    for (int i = 0; i < num; i++) {
+        const int vi = sc->sel[i];
+        float c = view_cost<HR, STRICT, QUAD>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;
+        if (c <= cmin) { cmin = c; bv = vi; }   // last view attaining the minimum (gipuma.cu:506-510)
+        float v = c;
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const float lo = fminf(best[k], v), hi = fmaxf(best[k], v);
+            best[k] = lo;
+            v = hi;
+        }
+    }
+    int nb = valid;
+    if (sc->cost_comb == TSAR_COMB_BEST_N) nb = min(nb, sc->n_best);
+    if (nb <= 0) { beview = -1; ratio = 0.f; return TSAR_MAXCOST; }
+    float cost = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+        if (k < nb) cost += best[k];
+    cost = cost / (float)nb;
+    ratio = num >= 2 ? best[0] / best[1] : 0.f;
+    beview = bv;
+    return cost;
+}
+
+// XCD-aware tile order (guide §5.5 T1): workgroups are dealt round-robin to the 8 XCDs, so remap the
+// linear id such that each XCD walks one contiguous band of tiles and neighbouring tiles (which share
+// reference halo and source footprints) hit the same 4 MiB L2.  Bijective for any n.
+DEVFN int xcd_tile(int bid, int n) {
+    const int chunk = n >> 3, rem = n & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    return xcd * chunk + min(xcd, rem) + slot;
+}

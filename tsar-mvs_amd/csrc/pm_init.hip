@@ -1,0 +1,106 @@
+// pm_init.hip — random plane initialisation (gipuma_init_cu2, reference gipuma.cu:678-729) and the
+// diagnostic "score these planes" kernel (pmCostMultiview_cu over a caller-supplied plane map).
+// Both visit every pixel: region 32 x 8 per 256-thread workgroup.
+#include "pm_core.h"
+
+#define FULL_RH 8
+size_t pm_lds_bytes(int hr, int vr, int region_h);
+
+template <int NB, int HR, bool STRICT, bool QUAD, bool INIT>
+__global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __restrict__ sc, const float4* __restrict__ planes_in,
+                                                           float* __restrict__ c_out, float4* __restrict__ n_out,
+                                                           int32_t* __restrict__ beview_out, float* __restrict__ ratio_out, int tiles_x,
+                                                           int n_tiles) {
+    extern __shared__ float lds[];
+    const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
+    const int tw = PM_RW + 2 * hr, th = FULL_RH + 2 * vr;
+    float* tile = lds;
+    float* wts = lds + tw * th + threadIdx.x;
+    const int t = xcd_tile(blockIdx.x, n_tiles);
+    const int ty0 = (t / tiles_x) * FULL_RH, tx0 = (t % tiles_x) * PM_RW;
+    stage_ref_tile<FULL_RH>(sc, tile, tx0, ty0, hr, vr);
+    __syncthreads();
+    const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
+    const int x = tx0 + lx, y = ty0 + ly;
+    const int w = sc->w, h = sc->h;
+    if (x >= w || y >= h) return;
+    const int p = y * w + x;
+    const int own = (ly + vr) * tw + lx + hr;
+    const DevRef& rf = sc->ref;
+
+    float4 n4;
+    if (INIT) {
+        float vv[3];
+        view_vector(rf, x, y, vv);
+        Rand4 rn = philox_uniform4((uint32_t)p, 0u, 0u, sc->seed_lo, sc->seed_hi);
+        const float disp = between(rn.u[0], sc->min_disp, sc->max_disp);
+        // rndUnitVectorSphereMarsaglia_cu gipuma.cu:118-132
+        float a = between(rn.u[1], -1.0f, 1.0f), b = between(rn.u[2], -1.0f, 1.0f);
+        float sum = fma_(a, a, b * b);
+        for (uint32_t call = 1; sum >= 1.0f && call < 16; call++) {
+            rn = philox_uniform4((uint32_t)p, 0u, call, sc->seed_lo, sc->seed_hi);
+            a = between(rn.u[0], -1.0f, 1.0f); b = between(rn.u[1], -1.0f, 1.0f);
+            sum = fma_(a, a, b * b);
+            if (sum >= 1.0f) {
+                a = between(rn.u[2], -1.0f, 1.0f); b = between(rn.u[3], -1.0f, 1.0f);
+                sum = fma_(a, a, b * b);
+            }
+        }
+        if (sum >= 1.0f) { a = 0.f; b = 0.f; sum = 0.f; }
+        const float sq = sqrtf(1.0f - sum);
+        float n[3] = {2.0f * a * sq, 2.0f * b * sq, 1.0f - 2.0f * sum};
+        if (dot3(n, vv) > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }   // vecOnHemisphere_cu :106-112
+        const float depth = rf.f * rf.baseline / disp;
+        n4.x = n[0]; n4.y = n[1]; n4.z = n[2];
+        n4.w = plane_offset(rf, n, x, y, depth);
+        n_out[p] = n4;
+    } else {
+        n4 = planes_in[p];
+    }
+    const PixelRef pr = hoist_reference<HR>(tile, tw, own, wts, hr, vr);
+    float cost = TSAR_MAXCOST, rt = 0.f;
+    int bv = -1;
+    if (pr.textured) cost = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, n4, bv, rt);
+    c_out[p] = cost;
+    if (!INIT) {
+        if (beview_out) beview_out[p] = bv;
+        if (ratio_out) ratio_out[p] = rt;
+    }
+}
+
+template <int NB, int HR, bool STRICT, bool QUAD, bool INIT>
+static int launch_full_t(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
+    const DevScene& hs = ctx->hscene;
+    const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + FULL_RH - 1) / FULL_RH;
+    const int n_tiles = tiles_x * tiles_y;
+    const size_t lds = pm_lds_bytes(hs.hrad, hs.vrad, FULL_RH);
+    auto kern = pm_full_kernel<NB, HR, STRICT, QUAD, INIT>;
+    if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        ScopedKernelTimer tm(ctx, INIT ? "pm_init" : "pm_cost_planes");
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, planes, c, n, bv, rt, tiles_x, n_tiles);
+    }
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
+template <int NB, int HR, bool INIT>
+static int launch_full_nh(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
+    const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
+    if (strict) return quad ? launch_full_t<NB, HR, true, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, true, false, INIT>(ctx, planes, c, n, bv, rt);
+    return quad ? launch_full_t<NB, HR, false, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, false, false, INIT>(ctx, planes, c, n, bv, rt);
+}
+
+template <bool INIT>
+static int launch_full(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
+    const DevScene& hs = ctx->hscene;
+    const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;
+    const bool r5 = hs.hrad == 5 && hs.vrad == 5;
+    if (need <= 2) return r5 ? launch_full_nh<2, 5, INIT>(ctx, planes, c, n, bv, rt) : launch_full_nh<2, 0, INIT>(ctx, planes, c, n, bv, rt);
+    return r5 ? launch_full_nh<32, 5, INIT>(ctx, planes, c, n, bv, rt) : launch_full_nh<32, 0, INIT>(ctx, planes, c, n, bv, rt);
+}
+
+int launch_pm_init(tsar_ctx* ctx) { return launch_full<true>(ctx, nullptr, ctx->buf[0].c, ctx->buf[0].n4, nullptr, nullptr); }
+int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio) {
+    return launch_full<false>(ctx, planes, cost, nullptr, beview, ratio);
+}

@@ -1,0 +1,241 @@
+// pm_sweep.hip — one red/black half-iteration of PatchMatch: spatial propagation + plane refinement
+// of every pixel of one checkerboard colour, fused into ONE launch.
+//
+// Replaces gipuma_{black,red}_spatialProp_cu + gipuma_{black,red}_planeRefine_cu
+// (reference gipuma.cu:846-1138; host loop :1744-1754 issues 4 launches + 4 device syncs per
+// iteration, here 2 launches and no sync).  Refinement touches only the thread's own pixel, so fusing
+// it behind propagation does not change any value.
+//
+// Determinism: neighbours are read from the launch-start state.  Opposite-colour pixels are not
+// written by this launch; same-colour pixels (the six "V" taps of each near arm,
+// gipuma.cu:958-1034) are read from `same_in` while results go to `same_out` (ping-pong), where the
+// reference reads and writes the same array concurrently.
+#include "pm_core.h"
+
+#define SWEEP_RH 16  // region 32 x 16 pixels = 256 pixels of the active colour
+
+struct Candidate {
+    int idx;    // pixel index of the neighbour whose plane is tried, -1 = arm skipped
+    int same;   // 1 if that neighbour has the active colour (read from same_in)
+};
+
+// 8-arm adaptive candidate selection, gipuma.cu:874-1042.
+DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __restrict__ c_same, const float* __restrict__ c_other,
+                             int x, int y, Candidate cand[8]) {
+    const int col = sc->w, row = sc->h;
+    const int p = y * col + x;
+    const bool fix_seed = sc->flags & TSAR_FLAG_FIX_DOWN_FAR_SEED, fix_cmp = sc->flags & TSAR_FLAG_FIX_RIGHT_FAR_CMP;
+    float cmin;
+    int cp, cs;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cand[k].idx = -1; cand[k].same = 0; }
+    // far arms: offsets 3, 5, ..., 23 along the axis -> always the other colour
+    if (y > 2) {
+        cp = p - 3 * col; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 1; i < 11; ++i)
+            if (y > 2 + 2 * i) { const int q = p - (3 + 2 * i) * col; const float v = c_other[q]; if (v < cmin) { cmin = v; cp = q; } }
+        cand[0].idx = cp;
+    }
+    if (y < row - 3) {
+        cp = p + 3 * col;
+        cmin = (fix_seed || y <= 2) ? c_other[cp] : c_other[p - 3 * col];   // gipuma.cu:906 seeds with c[up_far]
+#pragma unroll
+        for (int i = 1; i < 11; ++i)
+            if (y < row - 3 - 2 * i) { const int q = p + (3 + 2 * i) * col; const float v = c_other[q]; if (v < cmin) { cmin = v; cp = q; } }
+        cand[1].idx = cp;
+    }
+    if (x > 2) {
+        cp = p - 3; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 1; i < 11; ++i)
+            if (x > 2 + 2 * i) { const int q = p - 3 - 2 * i; const float v = c_other[q]; if (v < cmin) { cmin = v; cp = q; } }
+        cand[2].idx = cp;
+    }
+    if (x < col - 3) {
+        cp = p + 3; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 1; i < 11; ++i)
+            if (x < col - 3 - 2 * i) {
+                const int q = p + 3 + 2 * i;
+                const float v = c_other[q];
+                const bool take = fix_cmp ? (v < cmin) : (cmin < v);             // gipuma.cu:943 is inverted
+                if (take) { cmin = v; cp = q; }
+            }
+        cand[3].idx = cp;
+    }
+    // near arms: the 4-neighbour (other colour) and three V pairs (same colour)
+    if (y > 0) {
+        cp = p - col; cs = 0; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (y > 1 + i && x > i) { const int q = p - (2 + i) * col - i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+            if (y > 1 + i && x < col - 1 - i) { const int q = p - (2 + i) * col + i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+        }
+        cand[4].idx = cp; cand[4].same = cs;
+    }
+    if (y < row - 1) {
+        cp = p + col; cs = 0; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (y < row - 2 - i && x > i) { const int q = p + (2 + i) * col - i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+            if (y < row - 2 - i && x < col - 1 - i) { const int q = p + (2 + i) * col + i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+        }
+        cand[5].idx = cp; cand[5].same = cs;
+    }
+    if (x > 0) {
+        cp = p - 1; cs = 0; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (x > 1 + i && y > i) { const int q = p - (2 + i) - i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+            if (x > 1 + i && y < row - 1 - i) { const int q = p - (2 + i) + i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+        }
+        cand[6].idx = cp; cand[6].same = cs;
+    }
+    if (x < col - 1) {
+        cp = p + 1; cs = 0; cmin = c_other[cp];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (x < col - 2 - i && y > i) { const int q = p + (2 + i) - i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+            if (x < col - 2 - i && y < row - 1 - i) { const int q = p + (2 + i) + i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
+        }
+        cand[7].idx = cp; cand[7].same = cs;
+    }
+}
+
+template <int NB, int HR, bool STRICT, bool QUAD>
+__global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
+                                                            const float* __restrict__ c_same, const float4* __restrict__ n_same,
+                                                            const float* __restrict__ c_other, const float4* __restrict__ n_other,
+                                                            float* c_out, float4* n_out, float* __restrict__ ratio_out,
+                                                            int32_t* __restrict__ beview_out, uint32_t stream_id, int do_prop,
+                                                            int do_refine, int tiles_x, int n_tiles) {
+    extern __shared__ float lds[];
+    const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
+    const int tw = PM_RW + 2 * hr, th = SWEEP_RH + 2 * vr;
+    float* tile = lds;
+    float* wts = lds + tw * th + threadIdx.x;
+
+    const int t = xcd_tile(blockIdx.x, n_tiles);
+    const int ty0 = (t / tiles_x) * SWEEP_RH, tx0 = (t % tiles_x) * PM_RW;
+    stage_ref_tile<SWEEP_RH>(sc, tile, tx0, ty0, hr, vr);
+    __syncthreads();
+
+    const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int y = ty0 + ly;
+    const int lx = 2 * k + ((colour + y) & 1);     // (x + y) & 1 == colour; gipuma.cu:1099-1103 / :1121-1125
+    const int x = tx0 + lx;
+    const int w = sc->w, h = sc->h;
+    if (x >= w || y >= h) return;
+    const int p = y * w + x;
+    const int own = (ly + vr) * tw + lx + hr;
+
+    float cost_now = c_same[p];
+    float4 n_now = n_same[p];
+    const PixelRef pr = hoist_reference<HR>(tile, tw, own, wts, hr, vr);
+    bool wrote = false;
+    float ratio_w = 0.f;
+    int beview_w = 0;
+    if (pr.textured) {
+        const DevRef& rf = sc->ref;
+        float depth_now = plane_depth(rf, n_now, x, y);
+        if (do_prop) {
+            Candidate cand[8];
+            select_candidates(sc, c_same, c_other, x, y, cand);
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                if (cand[a].idx < 0) continue;
+                const float4 nb = cand[a].same ? n_same[cand[a].idx] : n_other[cand[a].idx];
+                const float depth_b = plane_depth(rf, nb, x, y);
+                // spatialPropagation_cu gipuma.cu:524-566; the range test is done first: a
+                // hypothesis outside [depthMin, depthMax] is never accepted, so it is not scored.
+                if (!(depth_b >= rf.depthMin && depth_b <= rf.depthMax)) continue;
+                int bv; float rt;
+                const float cost_b = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, nb, bv, rt);
+                if (cost_b < cost_now) {
+                    cost_now = cost_b; n_now = nb; depth_now = depth_b;
+                    ratio_w = rt; beview_w = bv; wrote = true;
+                }
+            }
+        }
+        if (do_refine) {
+            // planeRefinement_cu gipuma.cu:621-676 + getRndDispAndUnitVector_cu :582-619
+            float vv[3];
+            view_vector(rf, x, y, vv);
+            float deltaN = 1.0f;
+            float deltaZ = sc->max_disp / 2.0f;
+            const float fb = rf.f * rf.baseline;
+            for (int step = 0; step < sc->refine_steps; step++) {
+                const Rand4 rn = philox_uniform4((uint32_t)p, stream_id, (uint32_t)step, sc->seed_lo, sc->seed_hi);
+                const float disp = fb / depth_now;
+                const float minDelta = -fminf(deltaZ, sc->min_disp + disp);   // "+" as written, gipuma.cu:601
+                const float maxDelta = fminf(deltaZ, sc->max_disp - disp);
+                const float dz = between(rn.u[0], minDelta, maxDelta);
+                const float dispOut = fminf(fmaxf(disp + dz, sc->min_disp), sc->max_disp);
+                const float depthOut = fb / dispOut;
+                float nt[3];
+                nt[0] = n_now.x + between(rn.u[1], -deltaN, deltaN);
+                nt[1] = n_now.y + between(rn.u[2], -deltaN, deltaN);
+                nt[2] = n_now.z + between(rn.u[3], -deltaN, deltaN);
+                const float inv = 1.0f / sqrtf(dot3(nt, nt));
+                nt[0] *= inv; nt[1] *= inv; nt[2] *= inv;
+                if (dot3(nt, vv) > 0.0f) { nt[0] = -nt[0]; nt[1] = -nt[1]; nt[2] = -nt[2]; }
+                float4 n_t;
+                n_t.x = nt[0]; n_t.y = nt[1]; n_t.z = nt[2];
+                n_t.w = plane_offset(rf, nt, x, y, depthOut);
+                int bv; float rt;
+                const float cost_t = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
+                if (cost_t < cost_now) {
+                    cost_now = cost_t; n_now = n_t; depth_now = depthOut;
+                    ratio_w = rt; beview_w = bv; wrote = true;
+                }
+                deltaN = deltaN / 4.0f;
+                deltaZ = deltaZ / 10.0f;
+            }
+        }
+    }
+    c_out[p] = cost_now;
+    n_out[p] = n_now;
+    if (wrote) { ratio_out[p] = ratio_w; beview_out[p] = beview_w; }
+}
+
+size_t pm_lds_bytes(int hr, int vr, int region_h) {
+    const int taps = (hr + 1) * (vr + 1);
+    return sizeof(float) * ((size_t)(PM_RW + 2 * hr) * (region_h + 2 * vr) + (size_t)taps * PM_BLOCK);
+}
+
+template <int NB, int HR, bool STRICT, bool QUAD>
+static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
+                          uint32_t stream_id, int do_prop, int do_refine) {
+    const DevScene& hs = ctx->hscene;
+    const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
+    const int n_tiles = tiles_x * tiles_y;
+    const size_t lds = pm_lds_bytes(hs.hrad, hs.vrad, SWEEP_RH);
+    auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD>;
+    if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        ScopedKernelTimer tm(ctx, "pm_sweep");
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
+                           other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles);
+    }
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
+template <int NB, int HR>
+static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
+    const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
+    if (strict) return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
+    return quad ? launch_sweep_t<NB, HR, false, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, false, false>(ctx, colour, a, b, c, sid, dp, dr);
+}
+
+int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
+                    int do_prop, int do_refine) {
+    const DevScene& hs = ctx->hscene;
+    const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;
+    const bool r5 = hs.hrad == 5 && hs.vrad == 5;
+    if (need <= 2) return r5 ? launch_sweep_nh<2, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
+                             : launch_sweep_nh<2, 0>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
+    return r5 ? launch_sweep_nh<32, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
+              : launch_sweep_nh<32, 0>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
+}

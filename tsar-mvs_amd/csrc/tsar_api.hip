@@ -1,0 +1,628 @@
+// tsar_api.hip — the C ABI of include/tsar.h: context, device memory, camera algebra, call order.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "tsar_dev.h"
+
+// ---- kernel timing -------------------------------------------------------------------------------
+ScopedKernelTimer::ScopedKernelTimer(tsar_ctx* c, const char* name) : ctx(c) {
+    if (!ctx->timing) return;
+    for (auto& k : ctx->timers)
+        if (k.name == name) t = &k;
+    if (!t) {
+        ctx->timers.emplace_back();
+        ctx->timers.back().name = name;
+        t = &ctx->timers.back();
+    }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { t = nullptr; return; }
+    hipEventRecord(e0, ctx->stream);
+}
+ScopedKernelTimer::~ScopedKernelTimer() {
+    if (!t) return;
+    hipEventRecord(e1, ctx->stream);
+    // vector may have been reallocated between ctor and dtor only by another timer ctor; none nests.
+    t->pending.emplace_back(e0, e1);
+}
+static void drain_timers(tsar_ctx* ctx) {
+    for (auto& k : ctx->timers) {
+        for (auto& pr : k.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                k.total_ms += ms;
+                k.launches++;
+            }
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        k.pending.clear();
+    }
+}
+
+// ---- helpers -------------------------------------------------------------------------------------
+static int fail(tsar_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+template <typename T>
+static int dev_alloc(tsar_ctx* ctx, T** p, size_t n) {
+    if (*p) { hipFree(*p); *p = nullptr; }
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? TSAR_ERR_NOMEM : TSAR_ERR_HIP; }
+    return TSAR_OK;
+}
+template <typename T>
+static void dev_free(T*& p) {
+    if (p) hipFree(p);
+    p = nullptr;
+}
+static hipMemcpyKind in_kind(int mem) { return mem == TSAR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice; }
+static hipMemcpyKind out_kind(int mem) { return mem == TSAR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost; }
+#define CHECK_CTX(ctx) \
+    if (!(ctx)) return TSAR_ERR_INVALID; \
+    if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, TSAR_ERR_HIP, "hipSetDevice failed")
+#define NEED_VIEWS(ctx) if (!(ctx)->have_views) return fail(ctx, TSAR_ERR_STATE, "tsar_set_views has not been called")
+#define NEED_STATE(ctx) if (!(ctx)->have_state) return fail(ctx, TSAR_ERR_STATE, "no plane state: call tsar_pm_init, tsar_load_planes or tsar_set_plane first")
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != TSAR_OK) return rc_; } while (0)
+
+static void inv3(const double* m, double* o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double s = 1.0 / det;
+    o[0] = c00 * s; o[1] = (m[2] * m[7] - m[1] * m[8]) * s; o[2] = (m[1] * m[5] - m[2] * m[4]) * s;
+    o[3] = c01 * s; o[4] = (m[0] * m[8] - m[2] * m[6]) * s; o[5] = (m[2] * m[3] - m[0] * m[5]) * s;
+    o[6] = c02 * s; o[7] = (m[1] * m[6] - m[0] * m[7]) * s; o[8] = (m[0] * m[4] - m[1] * m[3]) * s;
+}
+static void mul3(const double* a, const double* b, double* o) {
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
+}
+static void scale_k(const float* K, double s, double* o) {  // scaleK cameraGeometryUtils.h:143-154
+    for (int i = 0; i < 9; i++) o[i] = K[i];
+    o[0] /= s; o[4] /= s; o[2] /= s; o[5] /= s;
+}
+
+// Camera re-origin algebra of getCameraParameters (cameraGeometryUtils.h:270-356), without the
+// decomposeProjectionMatrix round trip: K, R, t come straight from the cam files.
+static void derive_cameras(tsar_ctx* ctx, const tsar_camera* cams) {
+    DevScene& sc = ctx->hscene;
+    const double s = ctx->params.cam_scale > 0 ? ctx->params.cam_scale : 1.0;
+    double K0[9], R0t[9], t0[3];
+    scale_k(cams[0].K, s, K0);
+    for (int r = 0; r < 3; r++) {
+        t0[r] = cams[0].t[r];
+        for (int c = 0; c < 3; c++) R0t[3 * r + c] = cams[0].R[3 * c + r];
+    }
+    for (int v = 0; v < ctx->n_views; v++) {
+        double Kv[9], Rv[9], Rrel[9], trel[3];
+        scale_k(cams[v].K, s, Kv);
+        for (int i = 0; i < 9; i++) Rv[i] = cams[v].R[i];
+        mul3(Rv, R0t, Rrel);                                     // [R|t] [R0|t0]^-1
+        for (int r = 0; r < 3; r++) trel[r] = cams[v].t[r] - (Rrel[3 * r] * t0[0] + Rrel[3 * r + 1] * t0[1] + Rrel[3 * r + 2] * t0[2]);
+        if (v == 0) {                                            // the reference camera is exactly K[I|0]
+            for (int i = 0; i < 9; i++) Rrel[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            trel[0] = trel[1] = trel[2] = 0.0;
+        }
+        DevView& dv = sc.view[v];
+        for (int i = 0; i < 9; i++) { dv.K[i] = (float)Kv[i]; dv.R[i] = (float)Rrel[i]; }
+        for (int r = 0; r < 3; r++) dv.t[r] = (float)trel[r];
+        dv.pad_ = 0.f;
+        if (v == 0) {
+            DevRef& rf = sc.ref;
+            double Kinv[9], M[9], Minv[9];
+            inv3(Kv, Kinv);
+            mul3(K0, Rrel, M);                                   // P = K_ref [R|t] (cameraGeometryUtils.h:302)
+            inv3(M, Minv);
+            for (int i = 0; i < 9; i++) {
+                rf.K[i] = (float)Kv[i]; rf.Kinv[i] = (float)Kinv[i]; rf.Minv[i] = (float)Minv[i];
+                rf.Rorig[i] = cams[0].R[i];
+            }
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) rf.RorigInv[3 * r + c] = cams[0].R[3 * c + r];
+            for (int r = 0; r < 3; r++) {
+                rf.P34[r] = (float)(K0[3 * r] * trel[0] + K0[3 * r + 1] * trel[1] + K0[3 * r + 2] * trel[2]);
+                rf.C[r] = (float)(-(Rrel[r] * trel[0] + Rrel[3 + r] * trel[1] + Rrel[6 + r] * trel[2]));
+            }
+            rf.fx = (float)K0[0];
+            rf.f = (float)K0[0];
+            rf.alpha = (float)K0[0] / (float)K0[4];
+            rf.baseline = 1.0f;                                  // cameraGeometryUtils.h:309
+            rf.depthMin = ctx->params.depth_min;
+            rf.depthMax = ctx->params.depth_max;
+        }
+    }
+    // main.cpp:1393-1398
+    sc.min_disp = sc.ref.f * sc.ref.baseline / ctx->params.depth_max;
+    sc.max_disp = sc.ref.f * sc.ref.baseline / ctx->params.depth_min;
+    int steps = 0;
+    for (float dz = sc.max_disp / 2.0f; dz >= 0.01f; dz = dz / 10.0f) steps++;   // gipuma.cu:643-644
+    sc.refine_steps = steps;
+}
+
+static void fill_scene_params(tsar_ctx* ctx) {
+    DevScene& sc = ctx->hscene;
+    const tsar_params& p = ctx->params;
+    sc.hrad = (p.box_hsize - 1) / 2;   // gipuma.cu:858-859
+    sc.vrad = (p.box_vsize - 1) / 2;
+    sc.n_best = p.n_best;
+    sc.cost_comb = p.cost_comb;
+    sc.flags = p.flags;
+    sc.seed_lo = (uint32_t)p.seed;
+    sc.seed_hi = (uint32_t)(p.seed >> 32);
+}
+static int upload_scene(tsar_ctx* ctx) {
+    if (!ctx->dscene) TRY(dev_alloc(ctx, &ctx->dscene, 1));
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->dscene, &ctx->hscene, sizeof(DevScene), hipMemcpyHostToDevice, ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // hscene may be edited again by the caller's next call
+    return TSAR_OK;
+}
+
+// ---- lifecycle -----------------------------------------------------------------------------------
+extern "C" const char* tsar_version(void) { return "tsar-mvs_amd 0.1.0 (gfx950)"; }
+
+extern "C" int tsar_create(int device, tsar_ctx** out) {
+    if (!out) return TSAR_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TSAR_ERR_HIP;
+    if (device < 0 || device >= n) return TSAR_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return TSAR_ERR_HIP;
+    tsar_ctx* ctx = new (std::nothrow) tsar_ctx();
+    if (!ctx) return TSAR_ERR_NOMEM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TSAR_ERR_HIP; }
+    tsar_default_params(&ctx->params);
+    *out = ctx;
+    return TSAR_OK;
+}
+
+static void free_views(tsar_ctx* ctx) {
+    for (auto& p : ctx->img) dev_free(p);
+    for (auto& p : ctx->quad) dev_free(p);
+    ctx->img.clear();
+    ctx->quad.clear();
+}
+static void free_planes(tsar_ctx* ctx) {
+    for (int b = 0; b < 2; b++) { dev_free(ctx->buf[b].c); dev_free(ctx->buf[b].n4); }
+    dev_free(ctx->ratio); dev_free(ctx->depth); dev_free(ctx->scale); dev_free(ctx->lrdiff); dev_free(ctx->confid);
+    dev_free(ctx->fakedepth); dev_free(ctx->beview); dev_free(ctx->canny); dev_free(ctx->out4);
+}
+
+extern "C" int tsar_destroy(tsar_ctx* ctx) {
+    if (!ctx) return TSAR_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    free_views(ctx);
+    free_planes(ctx);
+    dev_free(ctx->dscene); dev_free(ctx->region_text); dev_free(ctx->region_size); dev_free(ctx->region_n4);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TSAR_OK;
+}
+extern "C" const char* tsar_last_error(const tsar_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" int tsar_get_stream(tsar_ctx* ctx, void** stream_out) {
+    if (!ctx || !stream_out) return TSAR_ERR_INVALID;
+    *stream_out = (void*)ctx->stream;
+    return TSAR_OK;
+}
+extern "C" int tsar_synchronize(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+
+// ---- inputs --------------------------------------------------------------------------------------
+extern "C" void tsar_default_params(tsar_params* p) {   // algorithmparameters.h:21-52
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->box_hsize = 19;
+    p->box_vsize = 19;
+    p->n_best = 2;
+    p->cost_comb = TSAR_COMB_BEST_N;
+    p->depth_min = 2.0f;     // camera.h:37-44
+    p->depth_max = 20.0f;
+    p->cam_scale = 1.0f;
+    p->flags = 0;
+    p->seed = 0;
+}
+
+extern "C" int tsar_set_params(tsar_ctx* ctx, const tsar_params* p) {
+    CHECK_CTX(ctx);
+    if (!p) return fail(ctx, TSAR_ERR_INVALID, "params is NULL");
+    if (p->box_hsize < 1 || p->box_vsize < 1 || p->box_hsize > 63 || p->box_vsize > 63) return fail(ctx, TSAR_ERR_INVALID, "box size must be in 1..63");
+    if (p->n_best < 1) return fail(ctx, TSAR_ERR_INVALID, "n_best must be >= 1");
+    if (p->cost_comb != TSAR_COMB_ALL && p->cost_comb != TSAR_COMB_BEST_N) return fail(ctx, TSAR_ERR_INVALID, "cost_comb must be TSAR_COMB_ALL or TSAR_COMB_BEST_N");
+    if (!(p->depth_min > 0.f) || !(p->depth_max > p->depth_min)) return fail(ctx, TSAR_ERR_INVALID, "need 0 < depth_min < depth_max");
+    if (!(p->cam_scale > 0.f)) return fail(ctx, TSAR_ERR_INVALID, "cam_scale must be > 0");
+    ctx->params = *p;
+    ctx->have_params = true;
+    fill_scene_params(ctx);
+    if (ctx->have_views) {
+        // depth range / scale feed the derived camera block: the views must be set again
+        ctx->have_views = false;
+        ctx->have_state = false;
+    }
+    return TSAR_OK;
+}
+
+extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
+    CHECK_CTX(ctx);
+    if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
+    if (n_views < 2 || n_views > TSAR_MAX_VIEWS) return fail(ctx, TSAR_ERR_INVALID, "n_views must be in 2..TSAR_MAX_VIEWS");
+    if (w < 8 || h < 8 || (int64_t)w * h > (int64_t)1 << 28) return fail(ctx, TSAR_ERR_INVALID, "image size out of range");
+    if (!gray || !cams) return fail(ctx, TSAR_ERR_INVALID, "gray/cams is NULL");
+    for (int v = 0; v < n_views; v++)
+        if (!gray[v]) return fail(ctx, TSAR_ERR_INVALID, "gray[v] is NULL");
+    ctx->have_views = false;
+    ctx->have_state = false;
+    ctx->have_out = false;
+    free_views(ctx);
+    const size_t np = (size_t)w * h;
+    if (w != ctx->w || h != ctx->h) free_planes(ctx);
+    ctx->w = w; ctx->h = h; ctx->n_views = n_views;
+    DevScene& sc = ctx->hscene;
+    sc.w = w; sc.h = h; sc.quad_pitch = w + 2;
+    ctx->img.assign(n_views, nullptr);
+    ctx->quad.assign(n_views, nullptr);
+    int* dflag = nullptr;
+    TRY(dev_alloc(ctx, &dflag, 1));
+    hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream);
+    for (int v = 0; v < n_views; v++) {
+        TRY(dev_alloc(ctx, &ctx->img[v], np));
+        TRY(dev_alloc(ctx, &ctx->quad[v], (size_t)(w + 2) * (h + 2)));
+        TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->img[v], gray[v], np * sizeof(float), in_kind(mem), ctx->stream));
+        TRY(launch_build_quad(ctx, ctx->img[v], ctx->quad[v], w, h, dflag));
+    }
+    int hflag = 0;
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(dflag);
+    sc.use_quad = hflag ? 0 : 1;
+    for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; }
+    if (!sc.use_quad)
+        for (auto& q : ctx->quad) dev_free(q);
+    derive_cameras(ctx, cams);
+    fill_scene_params(ctx);
+    sc.n_sel = n_views - 1;
+    for (int i = 0; i < sc.n_sel; i++) sc.sel[i] = i + 1;
+    // state planes (LineState::resize linestate.h:71-110)
+    for (int b = 0; b < 2; b++) {
+        if (!ctx->buf[b].c) TRY(dev_alloc(ctx, &ctx->buf[b].c, np));
+        if (!ctx->buf[b].n4) TRY(dev_alloc(ctx, &ctx->buf[b].n4, np));
+    }
+    float** fplanes[] = {&ctx->ratio, &ctx->depth, &ctx->scale, &ctx->lrdiff, &ctx->confid, &ctx->fakedepth};
+    for (float** fp : fplanes) {
+        if (!*fp) TRY(dev_alloc(ctx, fp, np));
+        TSAR_HIP_TRY(ctx, hipMemsetAsync(*fp, 0, np * sizeof(float), ctx->stream));
+    }
+    if (!ctx->beview) TRY(dev_alloc(ctx, &ctx->beview, np));
+    if (!ctx->canny) TRY(dev_alloc(ctx, &ctx->canny, np));
+    if (!ctx->out4) TRY(dev_alloc(ctx, &ctx->out4, np));
+    TSAR_HIP_TRY(ctx, hipMemsetAsync(ctx->beview, 0, np * sizeof(int32_t), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipMemsetAsync(ctx->canny, 0, np * sizeof(int32_t), ctx->stream));
+    TRY(upload_scene(ctx));
+    ctx->have_views = true;
+    return TSAR_OK;
+}
+
+extern "C" int tsar_set_view_subset(tsar_ctx* ctx, int n, const int32_t* view_idx) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (n < 1 || n > TSAR_MAX_VIEWS || !view_idx) return fail(ctx, TSAR_ERR_INVALID, "subset size out of range");
+    for (int i = 0; i < n; i++)
+        if (view_idx[i] < 1 || view_idx[i] >= ctx->n_views) return fail(ctx, TSAR_ERR_INVALID, "view index must be in 1..n_views-1");
+    ctx->hscene.n_sel = n;
+    for (int i = 0; i < n; i++) ctx->hscene.sel[i] = view_idx[i];
+    return upload_scene(ctx);
+}
+
+// ---- PatchMatch ----------------------------------------------------------------------------------
+extern "C" int tsar_pm_init(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    TRY(launch_pm_init(ctx));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_state = true;
+    ctx->have_out = false;
+    ctx->sweeps_done = 0;
+    return TSAR_OK;
+}
+
+static int pm_sweeps(tsar_ctx* ctx, int n_sweeps, int first_colour, int do_prop, int do_refine) {
+    // cur[k]: which ping-pong buffer holds the current values of colour k.  Both start in buf[0].
+    int cur[2] = {0, 0};
+    for (int s = 0; s < n_sweeps; s++) {
+        const int colour = (first_colour + s) & 1;
+        const PlaneBuf& same_in = ctx->buf[cur[colour]];
+        const PlaneBuf& other = ctx->buf[cur[colour ^ 1]];
+        const PlaneBuf& same_out = ctx->buf[cur[colour] ^ 1];
+        TRY(launch_pm_sweep(ctx, colour, same_in, other, same_out, 1u + (uint32_t)ctx->sweeps_done, do_prop, do_refine));
+        cur[colour] ^= 1;
+        ctx->sweeps_done++;
+    }
+    // make buf[0] canonical again
+    if (cur[0] == 1 && cur[1] == 1) {
+        std::swap(ctx->buf[0], ctx->buf[1]);
+    } else if (cur[0] != cur[1]) {
+        // odd number of sweeps: one colour lives in buf[1]; merge it back (diagnostic path only)
+        const size_t np = (size_t)ctx->w * ctx->h;
+        const int moved = cur[0] == 1 ? 0 : 1;
+        std::vector<float> c0(np), c1(np);
+        std::vector<float4> n0(np), n1(np);
+        TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        TSAR_HIP_TRY(ctx, hipMemcpy(c0.data(), ctx->buf[0].c, np * 4, hipMemcpyDeviceToHost));
+        TSAR_HIP_TRY(ctx, hipMemcpy(c1.data(), ctx->buf[1].c, np * 4, hipMemcpyDeviceToHost));
+        TSAR_HIP_TRY(ctx, hipMemcpy(n0.data(), ctx->buf[0].n4, np * 16, hipMemcpyDeviceToHost));
+        TSAR_HIP_TRY(ctx, hipMemcpy(n1.data(), ctx->buf[1].n4, np * 16, hipMemcpyDeviceToHost));
+        for (int y = 0; y < ctx->h; y++)
+            for (int x = 0; x < ctx->w; x++)
+                if (((x + y) & 1) == moved) { c0[(size_t)y * ctx->w + x] = c1[(size_t)y * ctx->w + x]; n0[(size_t)y * ctx->w + x] = n1[(size_t)y * ctx->w + x]; }
+        TSAR_HIP_TRY(ctx, hipMemcpy(ctx->buf[0].c, c0.data(), np * 4, hipMemcpyHostToDevice));
+        TSAR_HIP_TRY(ctx, hipMemcpy(ctx->buf[0].n4, n0.data(), np * 16, hipMemcpyHostToDevice));
+    }
+    return TSAR_OK;
+}
+
+extern "C" int tsar_pm_iterate(tsar_ctx* ctx, int iters) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    NEED_STATE(ctx);
+    if (iters < 0) return fail(ctx, TSAR_ERR_INVALID, "iters must be >= 0");
+    TRY(pm_sweeps(ctx, 2 * iters, 0, 1, 1));   // black then red, gipuma.cu:1744-1754
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_out = false;
+    return TSAR_OK;
+}
+
+// Diagnostics entry (not in the reference): one half-iteration with propagation and/or refinement.
+extern "C" int tsar_pm_sweep(tsar_ctx* ctx, int colour, int do_prop, int do_refine) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    NEED_STATE(ctx);
+    TRY(pm_sweeps(ctx, 1, colour & 1, do_prop, do_refine));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_out = false;
+    return TSAR_OK;
+}
+extern "C" int tsar_set_sweep_counter(tsar_ctx* ctx, int n) {
+    if (!ctx) return TSAR_ERR_INVALID;
+    ctx->sweeps_done = n;
+    return TSAR_OK;
+}
+
+extern "C" int tsar_pm_cost_planes(tsar_ctx* ctx, const float* planes, int mem, float* cost_out, int32_t* beview_out, float* ratio_out) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (!planes || !cost_out) return fail(ctx, TSAR_ERR_INVALID, "planes/cost_out is NULL");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    float4* dpl = nullptr;
+    float *dc = nullptr, *drt = nullptr;
+    int32_t* dbv = nullptr;
+    int rc = TSAR_OK;
+    if (mem == TSAR_MEM_DEVICE) {
+        rc = launch_pm_cost_planes(ctx, (const float4*)planes, cost_out, beview_out, ratio_out);
+        if (rc == TSAR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "sync failed");
+        return rc;
+    }
+    if ((rc = dev_alloc(ctx, &dpl, np)) == TSAR_OK && (rc = dev_alloc(ctx, &dc, np)) == TSAR_OK && (rc = dev_alloc(ctx, &drt, np)) == TSAR_OK &&
+        (rc = dev_alloc(ctx, &dbv, np)) == TSAR_OK) {
+        if (hipMemcpyAsync(dpl, planes, np * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "H2D failed");
+        if (rc == TSAR_OK) rc = launch_pm_cost_planes(ctx, dpl, dc, dbv, drt);
+        if (rc == TSAR_OK) {
+            hipMemcpyAsync(cost_out, dc, np * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (beview_out) hipMemcpyAsync(beview_out, dbv, np * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (ratio_out) hipMemcpyAsync(ratio_out, drt, np * 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "kernel or copy failed");
+        }
+    }
+    dev_free(dpl); dev_free(dc); dev_free(drt); dev_free(dbv);
+    return rc;
+}
+
+extern "C" int tsar_set_plane(tsar_ctx* ctx, const float* planes, const float* cost, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (!planes || !cost) return fail(ctx, TSAR_ERR_INVALID, "planes/cost is NULL");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[0].n4, planes, np * 16, in_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[0].c, cost, np * 4, in_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_state = true;
+    ctx->have_out = false;
+    return TSAR_OK;
+}
+extern "C" int tsar_get_plane(tsar_ctx* ctx, float* planes, float* cost, int32_t* beview, float* ratio, int mem) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    const size_t np = (size_t)ctx->w * ctx->h;
+    if (planes) TSAR_HIP_TRY(ctx, hipMemcpyAsync(planes, ctx->buf[0].n4, np * 16, out_kind(mem), ctx->stream));
+    if (cost) TSAR_HIP_TRY(ctx, hipMemcpyAsync(cost, ctx->buf[0].c, np * 4, out_kind(mem), ctx->stream));
+    if (beview) TSAR_HIP_TRY(ctx, hipMemcpyAsync(beview, ctx->beview, np * 4, out_kind(mem), ctx->stream));
+    if (ratio) TSAR_HIP_TRY(ctx, hipMemcpyAsync(ratio, ctx->ratio, np * 4, out_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+
+// ---- plane <-> depth -----------------------------------------------------------------------------
+template <typename T>
+struct TmpIn {   // device view of a caller buffer (copies host buffers in)
+    tsar_ctx* ctx;
+    const T* d = nullptr;
+    T* owned = nullptr;
+    int rc = TSAR_OK;
+    TmpIn(tsar_ctx* c, const T* src, size_t n, int mem) : ctx(c) {
+        if (!src) return;
+        if (mem == TSAR_MEM_DEVICE) { d = src; return; }
+        rc = dev_alloc(ctx, &owned, n);
+        if (rc == TSAR_OK && hipMemcpyAsync(owned, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "H2D failed");
+        d = owned;
+    }
+    ~TmpIn() {
+        if (owned) { hipStreamSynchronize(ctx->stream); hipFree(owned); }
+    }
+};
+
+extern "C" int tsar_load_planes(tsar_ctx* ctx, const float* depth, const float* normal_world, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (!depth || !normal_world) return fail(ctx, TSAR_ERR_INVALID, "depth/normal_world is NULL");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    TmpIn<float> d(ctx, depth, np, mem), n(ctx, normal_world, 3 * np, mem);
+    TRY(d.rc); TRY(n.rc);
+    TRY(launch_get_disp(ctx, d.d, n.d));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_state = true;
+    ctx->have_out = false;
+    return TSAR_OK;
+}
+extern "C" int tsar_compute_disp(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    TRY(launch_compute_disp(ctx));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_out = true;
+    return TSAR_OK;
+}
+extern "C" int tsar_compute_disp_final(tsar_ctx* ctx, const float* resize_planes, const float* text, int mem) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    if (!resize_planes || !text) return fail(ctx, TSAR_ERR_INVALID, "resize_planes/text is NULL");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    TmpIn<float> r(ctx, resize_planes, 4 * np, mem), t(ctx, text, np, mem);
+    TRY(r.rc); TRY(t.rc);
+    TRY(launch_compute_disp_final(ctx, (const float4*)r.d, t.d));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_out = true;
+    return TSAR_OK;
+}
+extern "C" int tsar_depth_to_plane(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    TRY(launch_depth_to_plane(ctx));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+extern "C" int tsar_get_result(tsar_ctx* ctx, float* depth, float* normal_world, float* cost, float* confid, int mem) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    if (!ctx->have_out) return fail(ctx, TSAR_ERR_STATE, "call tsar_compute_disp / tsar_fill_textureless first");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    if (depth || normal_world) {
+        if (mem == TSAR_MEM_DEVICE) {
+            TRY(launch_split_out4(ctx, depth, normal_world));
+        } else {
+            float *dd = nullptr, *dn = nullptr;
+            int rc = TSAR_OK;
+            if (depth) rc = dev_alloc(ctx, &dd, np);
+            if (rc == TSAR_OK && normal_world) rc = dev_alloc(ctx, &dn, 3 * np);
+            if (rc == TSAR_OK) rc = launch_split_out4(ctx, dd, dn);
+            if (rc == TSAR_OK && depth && hipMemcpyAsync(depth, dd, np * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "D2H failed");
+            if (rc == TSAR_OK && normal_world && hipMemcpyAsync(normal_world, dn, np * 12, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "D2H failed");
+            hipStreamSynchronize(ctx->stream);
+            dev_free(dd); dev_free(dn);
+            TRY(rc);
+        }
+    }
+    if (cost) TSAR_HIP_TRY(ctx, hipMemcpyAsync(cost, ctx->buf[0].c, np * 4, out_kind(mem), ctx->stream));
+    if (confid) TSAR_HIP_TRY(ctx, hipMemcpyAsync(confid, ctx->confid, np * 4, out_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+
+// ---- TSAR refinement -----------------------------------------------------------------------------
+extern "C" int tsar_set_reliable_mask(tsar_ctx* ctx, const float* scale, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (!scale) return fail(ctx, TSAR_ERR_INVALID, "scale is NULL");
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->scale, scale, (size_t)ctx->w * ctx->h * 4, in_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+extern "C" int tsar_getview(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    TRY(launch_getview(ctx));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+extern "C" int tsar_lrdiff(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    TRY(launch_lrdiff(ctx));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+extern "C" int tsar_set_regions(tsar_ctx* ctx, const int32_t* labels, int n_regions, const float* region_text, const float* region_size, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (!labels || !region_text || n_regions < 1) return fail(ctx, TSAR_ERR_INVALID, "labels/region_text is NULL or n_regions < 1");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->canny, labels, np * 4, in_kind(mem), ctx->stream));
+    TRY(dev_alloc(ctx, &ctx->region_text, (size_t)n_regions));
+    TRY(dev_alloc(ctx, &ctx->region_size, (size_t)n_regions));
+    TRY(dev_alloc(ctx, &ctx->region_n4, (size_t)n_regions));
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->region_text, region_text, (size_t)n_regions * 4, in_kind(mem), ctx->stream));
+    if (region_size) TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->region_size, region_size, (size_t)n_regions * 4, in_kind(mem), ctx->stream));
+    else TSAR_HIP_TRY(ctx, hipMemsetAsync(ctx->region_size, 0, (size_t)n_regions * 4, ctx->stream));
+    TSAR_HIP_TRY(ctx, hipMemsetAsync(ctx->region_n4, 0, (size_t)n_regions * 16, ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_regions = n_regions;
+    return TSAR_OK;
+}
+extern "C" int tsar_set_region_planes(tsar_ctx* ctx, const float* region_planes) {
+    CHECK_CTX(ctx);
+    if (ctx->n_regions < 1) return fail(ctx, TSAR_ERR_STATE, "tsar_set_regions has not been called");
+    if (!region_planes) return fail(ctx, TSAR_ERR_INVALID, "region_planes is NULL");
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->region_n4, region_planes, (size_t)ctx->n_regions * 16, hipMemcpyHostToDevice, ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+extern "C" int tsar_fake_depth(tsar_ctx* ctx, float* fakedepth_out, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (ctx->n_regions < 1) return fail(ctx, TSAR_ERR_STATE, "tsar_set_regions has not been called");
+    TRY(launch_fake_depth(ctx));
+    if (fakedepth_out) TSAR_HIP_TRY(ctx, hipMemcpyAsync(fakedepth_out, ctx->fakedepth, (size_t)ctx->w * ctx->h * 4, out_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
+extern "C" int tsar_fill_textureless(tsar_ctx* ctx) {   // gipuma_fill gipuma.cu:1819-1850
+    CHECK_CTX(ctx);
+    NEED_STATE(ctx);
+    if (ctx->n_regions < 1) return fail(ctx, TSAR_ERR_STATE, "tsar_set_regions has not been called");
+    TRY(launch_update_scale(ctx));
+    TRY(launch_compute_disp(ctx));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_out = true;
+    return TSAR_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+extern "C" int tsar_enable_kernel_timing(tsar_ctx* ctx, int enable) {
+    if (!ctx) return TSAR_ERR_INVALID;
+    ctx->timing = enable != 0;
+    return TSAR_OK;
+}
+extern "C" int tsar_reset_kernel_timing(tsar_ctx* ctx) {
+    CHECK_CTX(ctx);
+    hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    ctx->timers.clear();
+    return TSAR_OK;
+}
+extern "C" int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, int cap, int* n_out) {
+    CHECK_CTX(ctx);
+    if (!n_out) return fail(ctx, TSAR_ERR_INVALID, "n_out is NULL");
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    *n_out = (int)ctx->timers.size();
+    for (int i = 0; i < *n_out && i < cap && out; i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, ctx->timers[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = ctx->timers[i].launches;
+        out[i].total_ms = ctx->timers[i].total_ms;
+    }
+    return TSAR_OK;
+}

@@ -1,0 +1,124 @@
+// tsar_dev.h — device-visible scene description and the host context behind include/tsar.h.
+// gfx950 only; no CUDA / multi-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tsar.h"
+
+// One source view as the kernels read it: pose relative to the reference camera (ref = K[I|0]),
+// reference cameraGeometryUtils.h:270-302 / camera.h:9-33.
+struct DevView {
+    float K[9];
+    float R[9];
+    float t[3];
+    float pad_;
+    const float* img;        // [h][w] float gray
+    const uint32_t* quad;    // [(h+2)][(w+2)] packed 2x2 texel quads (8-bit images only), see tex_kernels.hip
+};
+
+// Reference camera block (camera.h:9-33 for cameras[REFERENCE]).
+struct DevRef {
+    float K[9];
+    float Kinv[9];
+    float Minv[9];
+    float Rorig[9];
+    float RorigInv[9];
+    float P34[3];
+    float C[3];
+    float fx, f, alpha, baseline, depthMin, depthMax;
+};
+
+// Everything a kernel needs besides the state planes.  Lives in device memory; every field is
+// wave-uniform, so reads become scalar loads.
+struct DevScene {
+    int w, h;
+    int n_sel;                 // viewSelectionSubsetNumber
+    int hrad, vrad;            // (box-1)/2, gipuma.cu:858-859
+    int n_best, cost_comb;
+    int refine_steps;          // iterations of the deltaZ loop, gipuma.cu:644
+    int quad_pitch;            // w + 2
+    int use_quad;              // all views are integral 0..255 -> 1-load bilinear taps
+    float min_disp, max_disp;
+    uint32_t flags;
+    uint32_t seed_lo, seed_hi;
+    DevRef ref;
+    int sel[TSAR_MAX_VIEWS];   // view indices in pair.txt order
+    DevView view[TSAR_MAX_VIEWS];
+};
+
+// State planes of one ping-pong buffer (linestate.h:12-13).
+struct PlaneBuf {
+    float* c;       // [h][w]
+    float4* n4;     // [h][w] (n_x, n_y, n_z, d), n.X + d = 0 in reference-camera coordinates
+};
+
+struct KernelTimer {
+    std::string name;
+    int launches = 0;
+    float total_ms = 0.f;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct tsar_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    tsar_params params{};
+    bool have_params = false, have_views = false, have_state = false;
+    int w = 0, h = 0, n_views = 0;
+    DevScene hscene{};          // host copy
+    DevScene* dscene = nullptr;  // device copy
+    std::vector<float*> img;     // device images (owned)
+    std::vector<uint32_t*> quad;
+    PlaneBuf buf[2]{};           // buf[0] is the canonical state outside tsar_pm_iterate
+    float *ratio = nullptr, *depth = nullptr, *scale = nullptr, *lrdiff = nullptr, *confid = nullptr, *fakedepth = nullptr;
+    int32_t *beview = nullptr, *canny = nullptr;
+    float4* out4 = nullptr;      // result of compute_disp: (n_world, depth)
+    bool have_out = false;
+    // regions (cannylines)
+    int n_regions = 0;
+    float *region_text = nullptr, *region_size = nullptr;
+    float4* region_n4 = nullptr;
+    int sweeps_done = 0;         // RNG stream counter
+    // timing
+    bool timing = false;
+    std::vector<KernelTimer> timers;
+};
+
+#define TSAR_HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                           \
+            return TSAR_ERR_HIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+// RAII bracket that records a hipEvent pair around a launch when timing is enabled.
+struct ScopedKernelTimer {
+    tsar_ctx* ctx;
+    KernelTimer* t = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ScopedKernelTimer(tsar_ctx* c, const char* name);
+    ~ScopedKernelTimer();
+};
+
+// ---- launchers implemented in the .hip files -----------------------------------------------------
+int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, int h, int* nonintegral_flag);
+int launch_pm_init(tsar_ctx* ctx);
+int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
+                    uint32_t stream_id, int do_prop, int do_refine);
+int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio);
+int launch_get_disp(tsar_ctx* ctx, const float* depth_in, const float* normal_world);
+int launch_compute_disp(tsar_ctx* ctx);
+int launch_compute_disp_final(tsar_ctx* ctx, const float4* resize4, const float* text);
+int launch_depth_to_plane(tsar_ctx* ctx);
+int launch_getview(tsar_ctx* ctx);
+int launch_lrdiff(tsar_ctx* ctx);
+int launch_update_scale(tsar_ctx* ctx);
+int launch_fake_depth(tsar_ctx* ctx);
+int launch_split_out4(tsar_ctx* ctx, float* depth, float* normal3);

@@ -1,0 +1,113 @@
+// tsar_device_math.h — per-hypothesis geometry and RNG for the gfx950 kernels.
+// Compiled with -ffp-contract=off: a fused multiply-add exists only where __builtin_fmaf is
+// written, every other operation is a single IEEE-754 fp32 operation (hipcc keeps '/' and sqrtf
+// correctly rounded without fast-math).  That makes all per-hypothesis quantities (planes, depths,
+// random perturbations) reproducible bit for bit on any IEEE machine.
+#pragma once
+#include "tsar_dev.h"
+
+#define DEVFN __device__ __forceinline__
+
+DEVFN float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DEVFN float dot3(const float* a, const float* b) { return fma_(a[2], b[2], fma_(a[1], b[1], a[0] * b[0])); }
+DEVFN void mat3vec(const float* m, const float* v, float* o) {
+    o[0] = dot3(m, v);
+    o[1] = dot3(m + 3, v);
+    o[2] = dot3(m + 6, v);
+}
+DEVFN void mat3mul(const float* a, const float* b, float* o) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[r * 3 + c] = fma_(a[r * 3 + 2], b[6 + c], fma_(a[r * 3 + 1], b[3 + c], a[r * 3] * b[c]));
+}
+
+// exp(x), x <= 0: bilateral weight (reference gipuma.cu:268).  Cody-Waite + degree-5 polynomial,
+// ~1 ulp; v_rndne + 9 fma, no v_exp_f32 so the value does not depend on the hardware's
+// transcendental unit.
+DEVFN float tsar_expf(float x) {
+    x = fmaxf(x, -87.0f);
+    float k = rintf(x * 1.44269504f);
+    float r = fma_(k, -0.693145752f, x);
+    r = fma_(k, -1.42860677e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    float y = fma_(p, r * r, r) + 1.0f;
+    return y * __uint_as_float((uint32_t)((int)k + 127) << 23);
+}
+
+// Philox4x32-10 counter-based generator: stateless (0 B/pixel; the reference keeps 48 B/pixel of
+// XORWOW state and re-seeds it from clock64() in every kernel, gipuma.cu:700,1077,1714).
+struct Rand4 {
+    float u[4];
+};
+DEVFN Rand4 philox_uniform4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1) {
+    uint32_t c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Rand4 o;
+    const float s = 5.9604644775390625e-8f;  // 2^-24 -> (0, 1] like curand_uniform
+    o.u[0] = (float)((c0 >> 8) + 1u) * s;
+    o.u[1] = (float)((c1 >> 8) + 1u) * s;
+    o.u[2] = (float)((c2 >> 8) + 1u) * s;
+    o.u[3] = (float)((c3 >> 8) + 1u) * s;
+    return o;
+}
+DEVFN float between(float u, float lo, float hi) { return fma_(u, hi - lo, lo); }  // curand_between gipuma.cu:113-116
+
+// getD_cu gipuma.cu:71-86: plane offset d such that the plane with normal n passes through the
+// point of pixel (x, y) at `depth`.
+DEVFN float plane_offset(const DevRef& rf, const float* n, int x, int y, float depth) {
+    float pt[3], X[3];
+    pt[0] = depth * (float)x - rf.P34[0];
+    pt[1] = depth * (float)y - rf.P34[1];
+    pt[2] = depth - rf.P34[2];
+    mat3vec(rf.Minv, pt, X);
+    return -dot3(n, X);
+}
+// getDisparity_cu / getDepthFromPlane3_cu gipuma.cu:436-453 (the value is a depth, the reference's
+// naming notwithstanding)
+DEVFN float plane_depth(const DevRef& rf, float nx, float ny, float nz, float d, int x, int y) {
+    if (d != d) return 1000.0f;
+    float den = fma_(nz, rf.fx, fma_(ny * ((float)y - rf.K[5]), rf.alpha, nx * ((float)x - rf.K[2])));
+    return (-d * rf.fx) / den;
+}
+DEVFN float plane_depth(const DevRef& rf, const float4& n4, int x, int y) { return plane_depth(rf, n4.x, n4.y, n4.z, n4.w, x, y); }
+// getViewVector_cu gipuma.cu:97-105
+DEVFN void view_vector(const DevRef& rf, int x, int y, float* v) {
+    float pt[3], X[3];
+    pt[0] = (float)x - rf.P34[0];
+    pt[1] = (float)y - rf.P34[1];
+    pt[2] = 1.0f - rf.P34[2];
+    mat3vec(rf.Minv, pt, X);
+    X[0] -= rf.C[0];
+    X[1] -= rf.C[1];
+    X[2] -= rf.C[2];
+    float inv = 1.0f / sqrtf(dot3(X, X));
+    v[0] = X[0] * inv;
+    v[1] = X[1] * inv;
+    v[2] = X[2] * inv;
+}
+// getHomography_cu gipuma.cu:207-224: H = K_src (R - t n^T / d) K_ref^-1
+DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n4, float* H) {
+    const float inv_d = 1.0f / n4.w;
+    const float n[3] = {n4.x, n4.y, n4.z};
+    float M[9], T[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) M[r * 3 + c] = vw.R[r * 3 + c] - (vw.t[r] * n[c]) * inv_d;
+    mat3mul(M, rf.Kinv, T);
+    mat3mul(vw.K, T, H);
+}

@@ -1,0 +1,35 @@
+"""Multi-GPU driver pieces: reference views are independent units, so they are dealt to the
+ranks with no data-path collective; the only exchange is the final gather of (depth, normal, cost) to
+the fusing rank.  The reference has no counterpart: it runs one process per view from a shell loop
+(reference scripts/courtyard.sh:29-48) and exchanges results through files."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+
+def shard_views(n_ref_views: int, world: int, rank: int) -> List[int]:
+    """Reference-view ids processed by `rank`: round-robin (all views of a scene cost the same)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return list(range(rank, n_ref_views, world))
+
+
+def owner_of_view(view: int, world: int) -> int:
+    return view % world
+
+
+def gather_results(dist, tensors: Sequence, dst: int = 0):
+    """Gather each rank's result tensors to `dst` (RCCL on GPUs, gloo in the CPU tests).
+    Returns on dst a list (per tensor) of lists (per rank); elsewhere None."""
+    import torch
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    out = []
+    for t in tensors:
+        if rank == dst:
+            bucket = [torch.empty_like(t) for _ in range(world)]
+            dist.gather(t, bucket, dst=dst)
+            out.append(bucket)
+        else:
+            dist.gather(t, None, dst=dst)
+    return out if rank == dst else None
