@@ -801,3 +801,8 @@ int orc_camera_sizeof(void) { return (int)sizeof(orc_camera); }
 float orc_min_disp(const orc_state *s) { return s->min_disp; }
 float orc_max_disp(const orc_state *s) { return s->max_disp; }
 void orc_set_launch(orc_state *s, int launch) { s->launch = launch; }
+
+/* raw Philox block for the published known-answer vectors (Random123 kat_vectors) */
+void orc_philox_raw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out) {
+    philox4x32(c0, c1, c2, c3, k0, k1, out);
+}

@@ -1,0 +1,69 @@
+"""N>1 host path on CPU: view sharding and the result gather, world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tsar_mvs_amd.driver import gather_results, owner_of_view, shard_views
+
+
+def test_shard_views_partitions_all_views():
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            mine = shard_views(44, world, r)
+            assert all(owner_of_view(v, world) == r for v in mine)
+            seen += mine
+        assert sorted(seen) == list(range(44))
+        sizes = [len(shard_views(44, world, r)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_views(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    views = shard_views(5, world, rank)
+    depth = torch.full((6, 8), float(rank + 1))
+    normal = torch.full((6, 8, 3), float(10 * (rank + 1)))
+    cost = torch.arange(48, dtype=torch.float32).reshape(6, 8) + rank
+    got = gather_results(dist, [depth, normal, cost], dst=0)
+    if rank == 0:
+        ok = len(got) == 3 and all(len(b) == world for b in got)
+        ok &= all(float(got[0][r][0, 0]) == r + 1 for r in range(world))
+        ok &= all(float(got[1][r][0, 0, 0]) == 10 * (r + 1) for r in range(world))
+        ok &= all(float(got[2][r][0, 1]) == 1 + r for r in range(world))
+        q.put((ok, views))
+    else:
+        assert got is None
+        q.put((True, views))
+    dist.destroy_process_group()
+
+
+def test_gather_results_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] for r in res)
+    assert sorted(sum((r[1] for r in res), [])) == [0, 1, 2, 3, 4]

@@ -1,0 +1,299 @@
+"""CPU tests that pin the oracle (and with it the semantics the HIP path is checked against) on answers
+known independently of this code base: published Philox vectors, closed-form geometry, libm, and
+hand-constructed propagation cases.  The reference has no tests or fixtures of its own and
+cannot be built here, so these — not reference outputs — are what the oracle is pinned by
+("parity unpinned")."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from tsar_mvs_amd import synth
+
+
+def _orc(scene, **kw):
+    return ol.Oracle([im.numpy() for im in scene.images], scene.K, scene.R, scene.t, scene.depth_min, scene.depth_max, **kw)
+
+
+def test_philox_published_vectors():
+    """Random123 known-answer vectors for philox4x32-10"""
+    L = ol.lib()
+    out = (C.c_uint32 * 4)()
+    L.orc_philox_raw(0, 0, 0, 0, 0, 0, out)
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    L.orc_philox_raw(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, out)
+    assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    L.orc_philox_raw(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0, out)
+    assert [hex(v) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_uniforms_are_in_half_open_unit_interval():
+    u = np.stack([ol.rng4(123, p, 1, s) for p in range(200) for s in range(4)])
+    assert u.min() > 0.0 and u.max() <= 1.0
+    assert abs(u.mean() - 0.5) < 0.03
+    # streams are distinct
+    assert not np.array_equal(ol.rng4(1, 5, 1, 0), ol.rng4(1, 5, 2, 0))
+    assert not np.array_equal(ol.rng4(1, 5, 1, 0), ol.rng4(2, 5, 1, 0))
+
+
+def test_expf_against_libm():
+    xs = np.linspace(-16.0, 0.0, 4001, dtype=np.float32)
+    got = np.array([ol.expf(float(x)) for x in xs], np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    ulp = np.abs(got.astype(np.float64) - ref) / np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert ulp.max() <= 1.5, ulp.max()
+    assert ol.expf(0.0) == 1.0
+
+
+def _two_view_wall(w=64, h=48, f=100.0, b=0.5, Z=5.0, seed=0):
+    """fronto-parallel textured wall at depth Z, source camera translated by b along x (the known-answer
+    configuration recorded in SURVEY §8c)"""
+    rng = np.random.default_rng(seed)
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+    big = rng.uniform(0, 255, size=(h, w + 64)).astype(np.float32)
+    # smooth a little so that bilinear sampling is meaningful, then quantise like an 8-bit image
+    big = (big + np.roll(big, 1, 1) + np.roll(big, 1, 0) + np.roll(big, -1, 1) + np.roll(big, -1, 0)) / 5.0
+    big = np.round(big)
+    d = int(round(f * b / Z))     # integer disparity: 10 px
+    ref = big[:, 32:32 + w].copy()
+    src = big[:, 32 - d:32 - d + w].copy()       # x_src = x_ref + d ... the point at ref x appears at x + f*t_x/Z
+    Ks = np.stack([K, K])
+    Rs = np.stack([np.eye(3, dtype=np.float32)] * 2)
+    ts = np.array([[0, 0, 0], [b, 0, 0]], np.float32)
+    return ref, src, Ks, Rs, ts, d
+
+
+def test_homography_of_fronto_parallel_plane_is_the_disparity_shift():
+    ref, src, K, R, t, d = _two_view_wall()
+    o = ol.Oracle([ref, src], K, R, t, 2.0, 20.0)
+    n4 = np.array([0, 0, -1, 5.0], np.float32)        # n.X + d = 0  ->  -Z + 5 = 0
+    H = o.homography(1, n4)
+    H = H / H[2, 2]
+    assert np.allclose(H, [[1, 0, 10.0], [0, 1, 0], [0, 0, 1]], atol=1e-4)
+    assert abs(o.depth_from_plane(n4, 20, 30) - 5.0) < 1e-5
+
+
+def test_true_plane_scores_zero_and_wrong_plane_does_not():
+    ref, src, K, R, t, d = _two_view_wall()
+    o = ol.Oracle([ref, src], K, R, t, 2.0, 20.0)
+    true_plane = np.array([0, 0, -1, 5.0], np.float32)
+    wrong_plane = np.array([0, 0, -1, 6.5], np.float32)   # 1.3 x depth
+    c_true = [o.pm_cost(1, x, y, true_plane) for x in range(12, 40, 3) for y in range(10, 38, 3)]
+    c_wrong = [o.pm_cost(1, x, y, wrong_plane) for x in range(12, 40, 3) for y in range(10, 38, 3)]
+    assert max(c_true) < 1e-5
+    assert np.median(c_wrong) > 0.5
+    # textureless window -> MAXCOST (kMinVar, reference gipuma.cu:289-291)
+    flat = np.zeros_like(ref)
+    o2 = ol.Oracle([flat, src], K, R, t, 2.0, 20.0)
+    assert o2.pm_cost(1, 30, 20, true_plane) == 2.0
+
+
+def test_window_taps_skip_the_centre_and_clamp_at_borders():
+    """WIN_INCREMENT 2 with an odd radius never samples the centre pixel (reference gipuma.cu:37,259-260):
+    changing only the centre pixel changes the cost only through the colour weights"""
+    ref, src, K, R, t, d = _two_view_wall()
+    o = ol.Oracle([ref, src], K, R, t, 2.0, 20.0)
+    n4 = np.array([0, 0, -1, 5.0], np.float32)
+    # border pixel: taps fall outside the image and are clamped, result finite and in range
+    c = o.pm_cost(1, 0, 0, n4)
+    assert 0.0 <= c <= 2.0
+    c = o.pm_cost(1, 63, 47, n4)
+    assert 0.0 <= c <= 2.0
+
+
+def test_plane_offset_depth_round_trip(small_scene):
+    o = _orc(small_scene)
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        x, y = int(rng.integers(0, small_scene.w)), int(rng.integers(0, small_scene.h))
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        if n @ o.view_vector(x, y) > 0:
+            n = -n
+        if abs(n @ o.view_vector(x, y)) < 0.2:
+            continue
+        depth = float(rng.uniform(small_scene.depth_min, small_scene.depth_max))
+        d = o.getD(n.astype(np.float32), x, y, depth)
+        back = o.depth_from_plane(np.array([*n, d], np.float32), x, y)
+        assert abs(back - depth) / depth < 2e-5
+    v = o.view_vector(10, 10)
+    assert abs(np.linalg.norm(v) - 1) < 1e-6 and v[2] > 0
+    assert o.depth_from_plane(np.array([0, 0, -1, np.nan], np.float32), 3, 3) == 1000.0   # gipuma.cu:449-450
+
+
+def test_camera_reorigin(small_scene):
+    """reference camera becomes K[I|0]; relative poses reproduce the original projections"""
+    sc = small_scene
+    o = _orc(sc)
+    c0 = o.camera(0)
+    assert np.allclose(np.array(c0.R).reshape(3, 3), np.eye(3))
+    assert np.allclose(c0.t, 0) and np.allclose(c0.C, 0) and np.allclose(c0.P34, 0)
+    assert np.allclose(np.array(c0.Minv).reshape(3, 3) @ sc.K[0], np.eye(3), atol=1e-5)
+    assert c0.baseline == 1.0 and abs(c0.alpha - 1.0) < 1e-6
+    # a world point seen by view 2: projecting through (R_rel, t_rel) from reference-camera coordinates
+    Xw = np.array([0.3, -0.2, 0.4])
+    Xr = sc.R[0].astype(np.float64) @ Xw + sc.t[0]
+    c2 = o.camera(2)
+    Xc = np.array(c2.R).reshape(3, 3) @ Xr + np.array(c2.t)
+    Xc_direct = sc.R[2].astype(np.float64) @ Xw + sc.t[2]
+    assert np.allclose(Xc, Xc_direct, atol=1e-5)
+    assert abs(o.min_disp - c0.f / sc.depth_max) < 1e-4 and abs(o.max_disp - c0.f / sc.depth_min) < 1e-4
+
+
+def test_multiview_best_n(small_scene):
+    sc = small_scene
+    gp = synth.gt_planes(sc).numpy()
+    x, y = 40, 30
+    per_view = sorted(min(_orc(sc).pm_cost(v, x, y, gp[y, x]), 2.0) for v in (1, 2, 3))
+    c1, bv1, rt1 = _orc(sc, n_best=1).pm_cost_multiview(x, y, gp[y, x])
+    c2, _, _ = _orc(sc, n_best=2).pm_cost_multiview(x, y, gp[y, x])
+    call, _, _ = _orc(sc, n_best=2, cost_comb=0).pm_cost_multiview(x, y, gp[y, x])
+    assert c1 == pytest.approx(per_view[0], abs=0)
+    assert c2 == pytest.approx(np.float32((np.float32(per_view[0]) + np.float32(per_view[1])) / np.float32(2)), abs=0)
+    assert call == pytest.approx(float(np.float32(np.float32(np.float32(per_view[0]) + np.float32(per_view[1])) + np.float32(per_view[2])) / np.float32(3)), rel=1e-6)
+    assert rt1 == pytest.approx(per_view[0] / per_view[1], rel=1e-6)
+    assert bv1 in (1, 2, 3)
+    # view subset restricts the views used
+    cs, bvs, _ = _orc(sc, n_best=1, subset=[2]).pm_cost_multiview(x, y, gp[y, x])
+    assert bvs == 2 and cs == _orc(sc).pm_cost(2, x, y, gp[y, x])
+
+
+def _cost_map(h, w, fill=1.0):
+    return np.full((h, w), fill, np.float32)
+
+
+def test_candidate_selection_far_arms_and_quirks(small_scene):
+    sc = small_scene
+    h, w = sc.h, sc.w
+    x, y = 40, 30
+    p = y * w + x
+    c = _cost_map(h, w)
+    c[y - 9, x] = 0.1      # up_far offsets are 3,5,...,23
+    c[y - 8, x] = 0.0      # even offset: never looked at
+    c[y, x - 23] = 0.2
+    c[y, x - 25] = 0.0     # beyond the 11th tap
+    o = _orc(sc)
+    cand = o.select_candidates(c, x, y)
+    assert cand[0] == p - 9 * w
+    assert cand[2] == p - 23
+    # right_far: the reference's comparison is inverted -> it walks to the LARGEST cost
+    c2 = _cost_map(h, w)
+    c2[y, x + 3] = 0.5
+    c2[y, x + 7] = 1.7
+    c2[y, x + 9] = 0.1
+    assert o.select_candidates(c2, x, y)[3] == p + 7
+    fixed = _orc(sc, flags=2)
+    assert fixed.select_candidates(c2, x, y)[3] == p + 9
+    # down_far: the reference seeds the running minimum with c[up_far]
+    c3 = _cost_map(h, w)
+    c3[y - 3, x] = 0.05          # up_far seed, smaller than anything below
+    c3[y + 5, x] = 0.3
+    assert o.select_candidates(c3, x, y)[1] == p + 3 * w        # nothing beats the (foreign) seed -> stays at down_far
+    assert _orc(sc, flags=1).select_candidates(c3, x, y)[1] == p + 5 * w
+
+
+def test_candidate_selection_near_arms_and_borders(small_scene):
+    sc = small_scene
+    h, w = sc.h, sc.w
+    o = _orc(sc)
+    x, y = 40, 30
+    p = y * w + x
+    c = _cost_map(h, w)
+    c[y - 3, x - 1] = 0.2      # up_near V tap i=1: (x-1, y-3)
+    c[y + 2, x] = 0.3          # down_near V tap i=0: (x, y+2)
+    c[y + 2, x - 4] = 0.1      # left_near V tap i=2: (x-4, y+2)
+    c[y - 1, x + 3] = 0.4      # right_near V tap i=1: (x+3, y-1)
+    cand = o.select_candidates(c, x, y)
+    assert cand[4] == p - 3 * w - 1
+    assert cand[5] == p + 2 * w
+    assert cand[6] == p - 4 + 2 * w
+    assert cand[7] == p + 3 - w
+    # image corners: arms that would leave the image are skipped
+    cand = o.select_candidates(c, 0, 0)
+    assert cand[0] == -1 and cand[2] == -1 and cand[4] == -1 and cand[6] == -1
+    assert cand[1] >= 0 and cand[3] >= 0 and cand[5] == w and cand[7] == 1
+    cand = o.select_candidates(c, w - 1, h - 1)
+    assert cand[1] == -1 and cand[3] == -1 and cand[5] == -1 and cand[7] == -1
+
+
+def test_bilinear_semantics():
+    img = np.arange(12, dtype=np.float32).reshape(3, 4) * 10
+    L = ol.lib()
+    f = lambda u, v: L.orc_bilinear(img.ctypes.data_as(C.c_void_p), 4, 3, C.c_float(u), C.c_float(v))
+    assert f(1, 1) == 50.0
+    assert f(1.5, 1) == 55.0
+    assert f(1, 1.5) == 70.0
+    assert f(-5, -5) == 0.0 and f(10, 10) == 110.0          # clamp addressing
+    assert f(3.5, 0) == 30.0                                # beyond the last column the edge texel repeats
+    assert f(float("nan"), 0) == 0.0                        # NaN coordinates are defined (clamped low)
+
+
+def test_refinement_step_count(small_scene):
+    o = _orc(small_scene)
+    n, dz = 0, o.max_disp / 2
+    while dz >= 0.01:
+        n += 1
+        dz /= 10
+    assert o.refine_steps() == n
+
+
+def test_patchmatch_converges_on_the_synthetic_scene(mid_scene):
+    sc = mid_scene
+    o = _orc(sc, seed=1)
+    o.pm_init()
+    c0 = float(o.c.mean())
+    o.pm_iterate(3)
+    assert float(o.c.mean()) < 0.25 * c0
+    d = o.compute_disp()[..., 3]
+    gt = sc.gt_depth.numpy()
+    assert (np.abs(d - gt) / gt < 0.02).mean() > 0.75
+    # normals of accepted planes face the camera
+    n = o.norm4[..., :3]
+    assert (n[..., 2] < 0.2).mean() > 0.95
+
+
+def test_sweep_is_jacobi_and_colour_restricted(small_scene):
+    """a black sweep leaves every red pixel untouched and does not depend on the visiting order"""
+    sc = small_scene
+    o = _orc(sc, seed=2)
+    o.pm_init()
+    before_c, before_n = o.c.copy(), o.norm4.copy()
+    o.pm_sweep(0)
+    yy, xx = np.mgrid[0:sc.h, 0:sc.w]
+    red = ((xx + yy) & 1) == 1
+    assert np.array_equal(o.c[red], before_c[red]) and np.array_equal(o.norm4[red], before_n[red])
+    assert (o.c[~red] <= before_c[~red]).all()              # greedy: cost never increases
+
+
+def test_load_planes_compute_disp_round_trip(small_scene):
+    sc = small_scene
+    o = _orc(sc)
+    n_world = np.ascontiguousarray((sc.gt_normal.numpy() @ sc.R[0]).astype(np.float32))
+    o.load_planes(sc.gt_depth.numpy(), n_world)
+    assert (o.c == 1.0).all()
+    out = o.compute_disp()
+    assert np.allclose(out[..., 3], sc.gt_depth.numpy(), rtol=2e-5)
+    assert np.allclose(out[..., :3], n_world, atol=2e-6)
+    o.c[0, 0] = 2.0
+    assert o.compute_disp()[0, 0, 3] == 0.0                 # MAXCOST pixels export depth 0 (gipuma.cu:838-841)
+
+
+def test_textureless_fill(small_scene):
+    sc = small_scene
+    h, w = sc.h, sc.w
+    o = _orc(sc, seed=4)
+    o.pm_init()
+    labels = np.zeros((h, w), np.int32)
+    labels[:, w // 2:] = 1
+    o.set_regions(labels, np.array([1.0, -1.0], np.float32))
+    plane = np.array([0.0, 0.0, 1.0, -6.0], np.float32)       # faces away from the camera: must be flipped
+    o.set_region_planes(np.stack([np.zeros(4, np.float32), plane]))
+    keep = o.norm4[:, : w // 2].copy()
+    o.update_scale()
+    assert np.array_equal(o.norm4[:, : w // 2], keep)
+    assert np.allclose(o.norm4[:, w // 2:], [0, 0, -1, 6.0])
+    assert (o.c[:, w // 2:] == 0).all() and (o.scale[:, w // 2:] == 1).all()
+    c0 = o.camera(0)
+    assert np.allclose(c0.f / o.depth[:, w // 2:], 6.0, rtol=1e-5)
