@@ -806,3 +806,245 @@ void orc_set_launch(orc_state *s, int launch) { s->launch = launch; }
 void orc_philox_raw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out) {
     philox4x32(c0, c1, c2, c3, k0, k1, out);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* weighted median filter, gipuma_WMF (gipuma.cu:1499-1698) and gipuma_WMF_Final (:1294-1497).
+ * Restated literally, including the bubble sort whose inner loop touches index `num` (one
+ * zero-initialised slot takes part and the largest element drops out of the first `num`, SURVEY
+ * quirk 12).  Neighbours are read from the launch-start copies (S2).  Where the reference would
+ * leave norm_mid uninitialised (cumulative weight never reaches wSum/2 in one of the normal
+ * component scans) the last sorted element is used.  exp -> orc_expf. */
+#define WMF_CAP 145
+typedef struct { float w[WMF_CAP], d[WMF_CAP], x[WMF_CAP], y[WMF_CAP], z[WMF_CAP], w1[WMF_CAP], w2[WMF_CAP], w3[WMF_CAP]; int n[WMF_CAP]; int num; } wmf_buf;
+
+static void wmf_sort(wmf_buf *b) {
+    const int num = b->num;
+    for (int i = 0; i < num; i++)
+        for (int j = 0; j < num - i; j++) {
+            if (b->d[j] > b->d[j + 1]) {
+                float t = b->w[j]; b->w[j] = b->w[j + 1]; b->w[j + 1] = t;
+                t = b->d[j]; b->d[j] = b->d[j + 1]; b->d[j + 1] = t;
+                int nn = b->n[j]; b->n[j] = b->n[j + 1]; b->n[j + 1] = nn;
+            }
+            if (b->x[j] > b->x[j + 1]) { float t = b->x[j]; b->x[j] = b->x[j + 1]; b->x[j + 1] = t; t = b->w1[j]; b->w1[j] = b->w1[j + 1]; b->w1[j + 1] = t; }
+            if (b->y[j] > b->y[j + 1]) { float t = b->y[j]; b->y[j] = b->y[j + 1]; b->y[j + 1] = t; t = b->w2[j]; b->w2[j] = b->w2[j + 1]; b->w2[j + 1] = t; }
+            if (b->z[j] > b->z[j + 1]) { float t = b->z[j]; b->z[j] = b->z[j + 1]; b->z[j + 1] = t; t = b->w3[j]; b->w3[j] = b->w3[j + 1]; b->w3[j + 1] = t; }
+        }
+}
+static float wmf_median(const float *v, const float *w, int num, float half) {
+    float acc = 0.f;
+    for (int i = 0; i < num; i++) {
+        acc += w[i];
+        if (acc >= half) return v[i];
+    }
+    return v[num - 1];
+}
+/* gathers the taps; returns wSum; fills the plane through the weighted-median-depth pixel */
+static int wmf_collect(const orc_state *s, const float *scale_in, const float *depth_in, const float *n_in, int x, int y,
+                       int radius, int gap, float sdiv, wmf_buf *b) {
+    const float *img = s->img[0];
+    memset(b, 0, sizeof(*b));
+    const float cen = texel(img, s->w, s->h, x, y);
+    int num = 0;
+    for (int i = -radius; i <= radius; i += gap)
+        for (int j = -radius; j <= radius; j += gap) {
+            int px = x + i, py = y + j;
+            if (px < 0 || px >= s->w || py < 0 || py >= s->h) continue;
+            size_t q = (size_t)py * s->w + px;
+            if (scale_in[q] != 1.0f) continue;
+            float cd = fabsf(img[q] - cen);
+            float sd = sqrtf((float)(i * i + j * j)) / sdiv;
+            float wt = orc_expf(-sd / 4.0f) * orc_expf(-cd / 9.0f);   /* sigma_spatial 2, sigma_color 3 */
+            b->w[num] = b->w1[num] = b->w2[num] = b->w3[num] = wt;
+            b->d[num] = depth_in[q]; b->n[num] = (int)q;
+            b->x[num] = n_in[4 * q]; b->y[num] = n_in[4 * q + 1]; b->z[num] = n_in[4 * q + 2];
+            num++;
+        }
+    b->num = num;
+    return num;
+}
+static int wmf_plane(const orc_state *s, const float *depth_in, wmf_buf *b, float *nm) {
+    const orc_camera *cm = &s->cam[0];
+    const int num = b->num;
+    wmf_sort(b);
+    float wSum = 0.f;
+    for (int i = 0; i < num; i++) wSum += b->w[i];
+    const float half = wSum / 2.f;
+    nm[0] = wmf_median(b->x, b->w1, num, half);
+    nm[1] = wmf_median(b->y, b->w2, num, half);
+    nm[2] = wmf_median(b->z, b->w3, num, half);
+    float acc = 0.f;
+    for (int i = 0; i < num; i++) {
+        acc += b->w[i];
+        if (acc >= half) {
+            int weimid = b->n[i];
+            float depth_mid = cm->f * cm->baseline / depth_in[weimid];
+            double nrm = (double)sqrtf(dot3f(nm, nm));
+            nm[0] = (float)((double)nm[0] / nrm); nm[1] = (float)((double)nm[1] / nrm); nm[2] = (float)((double)nm[2] / nrm);
+            nm[3] = getD(nm, weimid % s->w, weimid / s->w, depth_mid, cm);
+            return 1;
+        }
+    }
+    return 0;
+}
+/* one gipuma_WMF launch: marks every pixel reliable / unreliable */
+void orc_wmf_detect(orc_state *s, int iter) {
+    const orc_camera *cm = &s->cam[0];
+    const size_t np = (size_t)s->w * s->h;
+    const int po = 1 << iter, repo = 1 << (3 - iter);
+    const int radius = 80 / po, gap = 16 / po, ths = 24 / po;
+    float *scale_in = (float *)malloc(np * 4);
+    memcpy(scale_in, s->scale, np * 4);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < s->h; y++) {
+        wmf_buf b;
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            float nm[4];
+            int num = wmf_collect(s, scale_in, s->depth, s->norm4, x, y, radius, gap, (float)repo, &b);
+            if (num > 0 && wmf_plane(s, s->depth, &b, nm)) {
+                float depth_now = depth_from_plane(cm, nm, x, y);
+                float disp_now = cm->f * cm->baseline / depth_now;
+                float depth_org = depth_from_plane(cm, s->norm4 + 4 * p, x, y);
+                float disp_org = cm->f * cm->baseline / depth_org;
+                s->scale[p] = (fabsf(disp_now - disp_org) > (float)ths) ? 0.0f : 1.0f;   /* DEPTH_THS_MIN/MAX are 0 (:38-39) */
+            } else {
+                s->scale[p] = 0.0f;
+            }
+        }
+    }
+    free(scale_in);
+}
+/* one gipuma_WMF_Final launch: fills unreliable pixels of textured regions */
+void orc_wmf_fill(orc_state *s, int iter) {
+    const orc_camera *cm = &s->cam[0];
+    const size_t np = (size_t)s->w * s->h;
+    const int po = 1 << iter;
+    const int radius = 5 * po, gap = po, ths = 32 / po;
+    float *scale_in = (float *)malloc(np * 4), *depth_in = (float *)malloc(np * 4), *n_in = (float *)malloc(np * 16);
+    memcpy(scale_in, s->scale, np * 4); memcpy(depth_in, s->depth, np * 4); memcpy(n_in, s->norm4, np * 16);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < s->h; y++) {
+        wmf_buf b;
+        for (int x = 0; x < s->w; x++) {
+            size_t p = (size_t)y * s->w + x;
+            if (!(s->region_text[s->canny[p]] == 1.0f && scale_in[p] == 0.0f)) continue;
+            float nm[4];
+            int num = wmf_collect(s, scale_in, depth_in, n_in, x, y, radius, gap, (float)po, &b);
+            if (num < ths || num == 0) continue;
+            if (!wmf_plane(s, depth_in, &b, nm)) continue;
+            memcpy(s->norm4 + 4 * p, nm, 16);
+            float depth_now = depth_from_plane(cm, nm, x, y);
+            float disp = cm->f * cm->baseline / depth_now;
+            if (disp <= s->min_disp || disp >= s->max_disp) { s->scale[p] = 0.0f; s->depth[p] = s->min_disp; }
+            else { s->scale[p] = 1.0f; s->depth[p] = disp; }
+        }
+    }
+    free(scale_in); free(depth_in); free(n_in);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* region plane RANSAC, main.cpp:1520-1730 (+ calcLinePara :147-164).  Double precision as in the
+ * reference.  Deterministic choices (the reference uses rand() and a time-seeded shuffle):
+ *   - points are listed in raster order; regions with more than 50000 reliable pixels keep an
+ *     evenly spaced subset of 49999 (reference: random shuffle, then pop to < 50000);
+ *   - random indices / perturbations come from Philox: stage 1 draw k uses counter
+ *     (k, 0x52414E53, region, 0), stage 2 draw (round*4+scale) uses (.., 0x52414E54, region, 0);
+ *   - calcLinePara's first component is reproduced as written unless ORC_FLAG_FIX_PLANE_FIT. */
+#define ORC_FLAG_FIX_PLANE_FIT (1u << 3)
+static inline uint32_t rnd_index(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+static int count_inliers(const float *pts, int n, double a, double b, double c, double d, double thr) {
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+        double resid = fabs((double)pts[3 * i] * a + (double)pts[3 * i + 1] * b + (double)pts[3 * i + 2] * c + d);
+        if (resid < thr) cnt++;
+    }
+    return cnt;
+}
+/* pts: n x 3 floats.  out: plane (a,b,c,d) as floats + inlier count */
+int orc_ransac_points(const float *pts, int n, float region_size, uint64_t seed, uint32_t region, uint32_t flags, float *plane_out) {
+    double a = 0, b = 0, c = 1, d = -1;
+    int maximum = 0;
+    /* `float depth_abs = 0.0003 * sqrtf(size / 20)` (:1551-1552): double product rounded to float;
+     * every later `depth_abs += 0.0001` is a double add rounded back to float */
+    float depth_abs_f = (float)(0.0003 * (double)sqrtf(region_size / 20));
+    double depth_abs = depth_abs_f;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (n <= 0) { plane_out[0] = 0; plane_out[1] = 0; plane_out[2] = 1; plane_out[3] = -1; return 0; }
+    for (int k = 0; k < 10000; k++) {
+        uint32_t r[4];
+        philox4x32((uint32_t)k, 0x52414E53u, region, 0u, k0, k1, r);
+        const float *p1 = pts + 3 * rnd_index(r[0], (uint32_t)n), *p2 = pts + 3 * rnd_index(r[1], (uint32_t)n), *p3 = pts + 3 * rnd_index(r[2], (uint32_t)n);
+        double x1 = p1[0], y1 = p1[1], z1 = p1[2], x2 = p2[0], y2 = p2[1], z2 = p2[2], x3 = p3[0], y3 = p3[1], z3 = p3[2];
+        double ta = (flags & ORC_FLAG_FIX_PLANE_FIT) ? (y2 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1)
+                                                    : (y3 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1);
+        double tb = (x3 - x1) * (z2 - z1) - (x2 - x1) * (z3 - z1);
+        double tc = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1);
+        double td = -(ta * x1 + tb * y1 + tc * z1);
+        double sq = sqrt(ta * ta + tb * tb + tc * tc);
+        ta /= sq; tb /= sq; tc /= sq; td /= sq;
+        int cnt = count_inliers(pts, n, ta, tb, tc, td, depth_abs);
+        if (cnt >= maximum) { a = ta; b = tb; c = tc; d = td; maximum = cnt; }
+        if (k % 1000 == 0) {
+            double rat = (double)maximum / (double)n;
+            if (rat < 0.3 && depth_abs < 0.003) {
+                depth_abs_f = (float)((double)depth_abs_f + 0.0001); depth_abs = depth_abs_f;
+            } else {
+                int max2 = count_inliers(pts, n, a, b, c, d, (double)depth_abs_f + 0.0001);
+                if ((double)max2 > (double)maximum + (double)n * 0.02) { depth_abs_f = (float)((double)depth_abs_f + 0.0001); depth_abs = depth_abs_f; maximum = max2; }
+            }
+        }
+    }
+    for (int round = 0; round < 1000; round++) {
+        int sc = 0;
+        for (int j = 2000; j >= 2; j /= 10, sc++) {
+            uint32_t r[4];
+            philox4x32((uint32_t)(round * 4 + sc), 0x52414E54u, region, 0u, k0, k1, r);
+            int med = j / 2;
+            double da = (double)((int)rnd_index(r[0], (uint32_t)j) - med) / 10000;
+            double db = (double)((int)rnd_index(r[1], (uint32_t)j) - med) / 10000;
+            double dc = (double)((int)rnd_index(r[2], (uint32_t)j) - med) / 10000;
+            double dd = (double)((int)rnd_index(r[3], (uint32_t)j) - med) / 1000;
+            double ra = a + da, rb = b + db, rc = c + dc, rd = d + dd;
+            double sq = sqrt(ra * ra + rb * rb + rc * rc);
+            ra /= sq; rb /= sq; rc /= sq; rd /= sq;
+            int cnt = count_inliers(pts, n, ra, rb, rc, rd, depth_abs);
+            if (cnt >= maximum) { a = ra; b = rb; c = rc; d = rd; maximum = cnt; }
+        }
+    }
+    plane_out[0] = (float)a; plane_out[1] = (float)b; plane_out[2] = (float)c; plane_out[3] = (float)d;
+    return maximum;
+}
+/* gather (main.cpp:1527-1594) + fit for every textureless region; planes -> region_norm4 */
+void orc_ransac_regions(orc_state *s, float *inlier_ratio) {
+    const orc_camera *cm = &s->cam[0];
+    const size_t np = (size_t)s->w * s->h;
+    for (int rg = 0; rg < s->n_regions; rg++) {
+        if (inlier_ratio) inlier_ratio[rg] = 0.f;
+        if (s->region_text[rg] != -1.0f) continue;
+        int total = 0;
+        for (size_t p = 0; p < np; p++)
+            if (s->canny[p] == rg && s->scale[p] == 1.0f) total++;
+        int keep = total > 50000 ? 49999 : total;
+        float *pts = (float *)malloc((size_t)(keep > 0 ? keep : 1) * 12);
+        int i = 0, m = 0;
+        for (size_t p = 0; p < np; p++) {
+            if (!(s->canny[p] == rg && s->scale[p] == 1.0f)) continue;
+            int take = total > 50000 ? (int)(((int64_t)(i + 1) * keep) / total) > (int)(((int64_t)i * keep) / total) : 1;
+            i++;
+            if (!take) continue;
+            int x = (int)(p % s->w), y = (int)(p / s->w);
+            float depth = cm->f * cm->baseline / s->depth[p];
+            float pt[3] = {depth * (float)x - cm->P34[0], depth * (float)y - cm->P34[1], depth - cm->P34[2]};
+            /* main.cpp:1583-1591 writes the products out without fma */
+            pts[3 * m] = cm->Minv[0] * pt[0] + cm->Minv[1] * pt[1] + cm->Minv[2] * pt[2];
+            pts[3 * m + 1] = cm->Minv[3] * pt[0] + cm->Minv[4] * pt[1] + cm->Minv[5] * pt[2];
+            pts[3 * m + 2] = cm->Minv[6] * pt[0] + cm->Minv[7] * pt[1] + cm->Minv[8] * pt[2];
+            m++;
+        }
+        int best = orc_ransac_points(pts, m, s->region_size[rg], s->seed, (uint32_t)rg, s->flags, s->region_norm4 + 4 * (size_t)rg);
+        if (inlier_ratio) inlier_ratio[rg] = m > 0 ? (float)best / (float)m : 0.f;
+        free(pts);
+    }
+}
+float *orc_region_planes(orc_state *s) { return s->region_norm4; }

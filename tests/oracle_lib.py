@@ -65,8 +65,16 @@ def lib():
         for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_iterate", "orc_pm_cost_planes",
                   "orc_select_candidates", "orc_homography", "orc_view_vector", "orc_load_planes", "orc_compute_disp",
                   "orc_depth_to_plane", "orc_compute_disp_final", "orc_lrdiff", "orc_getview", "orc_fake_depth",
-                  "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch"):
+                  "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch", "orc_wmf_detect", "orc_wmf_fill",
+                  "orc_ransac_regions", "orc_slic", "orc_rgb2lab", "orc_philox_raw"):
             getattr(L, n).restype = None
+        L.orc_region_planes.restype = _f32p
+        L.orc_region_planes.argtypes = [C.c_void_p]
+        L.orc_ransac_points.restype = C.c_int
+        L.orc_ransac_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_cbrtf.restype = C.c_float
+        L.orc_cbrtf.argtypes = [C.c_float]
+        L.orc_slic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_refine_steps.restype = C.c_int
         L.orc_refine_steps.argtypes = [C.c_void_p]
         _lib = L
@@ -270,6 +278,18 @@ class Oracle:
     def update_scale(self):
         self.L.orc_update_scale(self.s)
 
+    def wmf_detect(self, it):
+        self.L.orc_wmf_detect(self.s, C.c_int(it))
+
+    def wmf_fill(self, it):
+        self.L.orc_wmf_fill(self.s, C.c_int(it))
+
+    def ransac_regions(self):
+        ratio = np.zeros(self.n_regions, np.float32)
+        self.L.orc_ransac_regions(self.s, _p(ratio))
+        planes = np.ctypeslib.as_array(self.L.orc_region_planes(self.s), shape=(self.n_regions, 4)).copy()
+        return planes, ratio
+
 
 def rng4(seed, pixel, stream, step):
     u = np.empty(4, np.float32)
@@ -279,3 +299,32 @@ def rng4(seed, pixel, stream, step):
 
 def expf(x):
     return float(lib().orc_expf(C.c_float(x)))
+
+
+def ransac_points(pts, region_size, seed=0, region=0, flags=0):
+    pts = np.ascontiguousarray(pts, np.float32)
+    plane = np.empty(4, np.float32)
+    best = lib().orc_ransac_points(_p(pts), len(pts), C.c_float(region_size), C.c_uint64(seed), C.c_uint32(region), C.c_uint32(flags), _p(plane))
+    return plane, int(best)
+
+
+def cbrtf(x):
+    return float(lib().orc_cbrtf(C.c_float(x)))
+
+
+def rgb2lab(bgra):
+    px = np.ascontiguousarray(bgra, np.uint8)
+    out = np.empty(4, np.float32)
+    lib().orc_rgb2lab(_p(px), _p(out))
+    return out
+
+
+def slic(bgra, spixel_size=20, iters=5, weight=5.0, connectivity=0, color_space=0, want_centers=False):
+    img = np.ascontiguousarray(bgra, np.uint8)
+    h, w = img.shape[:2]
+    labels = np.empty((h, w), np.int32)
+    lab = np.empty((h, w, 4), np.float32)
+    mw, mh = w // spixel_size, h // spixel_size
+    centers = np.empty((mw * mh, 8), np.float32)
+    lib().orc_slic(_p(img), w, h, spixel_size, iters, C.c_float(weight), connectivity, color_space, _p(labels), _p(lab), _p(centers))
+    return (labels, lab, centers) if want_centers else labels

@@ -287,3 +287,99 @@ def test_error_codes():
         m.set_params(api.default_params(depth_min=5.0, depth_max=1.0))
     assert e.value.code == api.TSAR_ERR_INVALID
     m.close()
+
+
+# ---- TSAR refinement: weighted median filter, region RANSAC, SLIC ---------------------------------
+def _prepared_pair(sc, seed, flags=0):
+    """oracle + matcher in the same converged-ish state with lines->depth filled (getview)"""
+    orc = _oracle(sc, seed=seed, flags=flags)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    orc.getview()
+    m = api.matcher_from_scene(sc, seed=seed, flags=flags | api.FLAG_STRICT_DIV)
+    m.set_plane(orc.norm4.copy(), orc.c.copy())
+    m.getview()
+    return orc, m
+
+
+def test_wmf_detect_and_fill_bit_exact(small_scene):
+    sc = small_scene
+    h, w = sc.h, sc.w
+    orc, m = _prepared_pair(sc, 8)
+    rng = np.random.default_rng(0)
+    scale = (rng.uniform(size=(h, w)) < 0.7).astype(np.float32)
+    orc.scale[:] = scale
+    m.set_reliable_mask(scale)
+    labels = np.zeros((h, w), np.int32)
+    labels[:, w // 2:] = 1
+    text = np.array([1.0, -1.0], np.float32)
+    orc.set_regions(labels, text)
+    m.set_regions(labels, text)
+    for it in range(4):
+        orc.wmf_detect(it)
+    m.wmf(4, False)
+    import ctypes as C
+    got_scale = np.empty((h, w), np.float32)
+    # scale is read back through the fill below; check detect through its effect on a final pass
+    for it in range(3):
+        orc.wmf_fill(it)
+    m.wmf(3, True)
+    planes, _, _, _ = m.get_plane()
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    m.compute_disp()
+    ref = orc.compute_disp()
+    assert np.array_equal(m.get_result(("depth",))["depth"], ref[..., 3])
+    m.close()
+
+
+def test_ransac_regions_bit_exact(mid_scene):
+    sc = mid_scene
+    h, w = sc.h, sc.w
+    orc, m = _prepared_pair(sc, 12)
+    # regions from the analytic primitives: back plane (0) textured, slanted plane (1) and sphere (2) "textureless"
+    labels = sc.gt_prim.numpy().astype(np.int32)
+    text = np.array([1.0, -1.0, -1.0], np.float32)
+    size = np.array([(labels == k).sum() for k in range(3)], np.float32)
+    gt = sc.gt_depth.numpy()
+    # reliable = pixels whose depth converged (like weak.png in the reference)
+    d = orc.compute_disp()[..., 3]
+    scale = (np.abs(d - gt) / gt < 0.01).astype(np.float32)
+    orc.scale[:] = scale
+    m.set_reliable_mask(scale)
+    orc.set_regions(labels, text, size)
+    m.set_regions(labels, text, size)
+    planes_ref, ratio_ref = orc.ransac_regions()
+    planes, ratio = m.ransac_regions()
+    assert np.array_equal(planes[1:].view(np.uint32), planes_ref[1:].view(np.uint32))
+    assert np.array_equal(ratio, ratio_ref)
+    # the slanted plane is recovered: normal parallel to the analytic one
+    n_gt = sc.gt_normal.numpy()[labels == 1].mean(0)
+    n_gt /= np.linalg.norm(n_gt)
+    n = planes[1, :3] / np.linalg.norm(planes[1, :3])
+    assert abs(float(n @ n_gt)) > 0.995
+    assert ratio[1] > 0.05    # inlier band 0.0003*sqrt(size/20) is tight for a 192x128 depth map
+    # fill the textureless regions with the fitted planes and export
+    orc.fake_depth(); orc.update_scale()
+    ref = orc.compute_disp()
+    m.fake_depth(); m.fill_textureless()
+    res = m.get_result()
+    assert np.array_equal(res["depth"], ref[..., 3])
+    m.close()
+
+
+@pytest.mark.parametrize("S,iters,conn,space", [(20, 5, 0, 0), (16, 3, 1, 0), (20, 2, 0, 1), (12, 2, 1, 2)])
+def test_slic_labels_exact(S, iters, conn, space):
+    rng = np.random.default_rng(S)
+    h, w = 150, 212
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0] = (127 + 100 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.uint8)
+    img[..., 1] = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
+    img[..., 2] = (rng.integers(0, 30, size=(h, w)) + 100 * ((xx // 40 + yy // 30) % 2)).astype(np.uint8)
+    m = api.Matcher()
+    st = api.SlicSettings(S, iters, 5.0, conn, space)
+    got = m.slic(img, st)
+    ref = ol.slic(img, S, iters, 5.0, conn, space)
+    assert np.array_equal(got, ref)
+    assert got.min() >= 0 and got.max() < (w // S) * (h // S)
+    m.close()

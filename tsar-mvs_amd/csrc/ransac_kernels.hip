@@ -1,0 +1,260 @@
+// ransac_kernels.hip — per-region plane fit of the TSAR "correlative refinement"
+// (reference main.cpp:1520-1730: single-threaded CPU RANSAC, ~7e8 point-plane residuals per region,
+// where the live pipeline's wall time goes; calcLinePara main.cpp:147-164).
+//
+// MI355X shape: (1) the reliable pixels of all textureless regions are compacted in raster order by a
+// device select + a stable radix sort by region (rocPRIM; plain library primitives), (2) one kernel
+// back-projects them to 3-D points, (3) ONE 1024-thread workgroup per region runs the whole
+// sequential hypothesise / count / adapt-threshold / perturb loop with block-wide inlier counts,
+// every region on its own CU concurrently.  Arithmetic is double precision in the reference's
+// operation order, so the result is reproducible bit for bit on the CPU oracle.
+//
+// Deterministic choices (the reference uses rand() and a time-seeded shuffle): raster-order point
+// lists, even subsampling to 49999 points above 50000, Philox draws keyed by (draw, stage, region).
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "tsar_device_math.h"
+
+#define TSAR_FLAG_FIX_PLANE_FIT (1u << 3)
+#define RS_BLOCK 1024
+#define RS_MAXPTS 49999
+
+struct ReliableTexturelessPixel {
+    const int32_t* canny;
+    const float* scale;
+    const int32_t* slot_of_region;
+    __device__ bool operator()(const uint32_t& p) const { return scale[p] == 1.0f && slot_of_region[canny[p]] >= 0; }
+};
+
+__global__ void ransac_keys_kernel(const uint32_t* __restrict__ pix, int n, const int32_t* __restrict__ canny,
+                                   const int32_t* __restrict__ slot_of_region, uint32_t* __restrict__ keys, int* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = (uint32_t)slot_of_region[canny[pix[i]]];
+    keys[i] = s;
+    atomicAdd(&counts[s], 1);
+}
+
+// main.cpp:1571-1594: depth from lines->depth (= f*b/depth), back-projection through M^-1
+__global__ void ransac_points_kernel(const DevScene* __restrict__ sc, const uint32_t* __restrict__ pix_sorted, const uint32_t* __restrict__ keys_sorted,
+                                     int n, const float* __restrict__ depth, const int* __restrict__ slot_start, const int* __restrict__ slot_total,
+                                     const int* __restrict__ pts_start, float* __restrict__ pts) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int s = (int)keys_sorted[q];
+    const int64_t i = q - slot_start[s], total = slot_total[s];
+    const int64_t keep = total > 50000 ? RS_MAXPTS : total;
+    const int64_t hi = ((i + 1) * keep) / total, lo = (i * keep) / total;
+    if (hi <= lo) return;
+    const DevRef& rf = sc->ref;
+    const uint32_t p = pix_sorted[q];
+    const int x = (int)(p % (uint32_t)sc->w), y = (int)(p / (uint32_t)sc->w);
+    const float dd = rf.f * rf.baseline / depth[p];
+    const float ptx = dd * (float)x - rf.P34[0], pty = dd * (float)y - rf.P34[1], ptz = dd - rf.P34[2];
+    float* o = pts + 3 * ((size_t)pts_start[s] + (size_t)(hi - 1));
+    o[0] = rf.Minv[0] * ptx + rf.Minv[1] * pty + rf.Minv[2] * ptz;
+    o[1] = rf.Minv[3] * ptx + rf.Minv[4] * pty + rf.Minv[5] * ptz;
+    o[2] = rf.Minv[6] * ptx + rf.Minv[7] * pty + rf.Minv[8] * ptz;
+}
+
+DEVFN void philox_raw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1, uint32_t r[4]) {
+    uint32_t c3 = 0u;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+DEVFN uint32_t rnd_index(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+
+// block-wide number of points with |ax + by + cz + d| < thr
+DEVFN int block_count(const float* __restrict__ pts, int n, double a, double b, double c, double d, double thr, int* sh) {
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += RS_BLOCK) {
+        const double resid = fabs((double)pts[3 * i] * a + (double)pts[3 * i + 1] * b + (double)pts[3 * i + 2] * c + d);
+        cnt += resid < thr;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_down(cnt, o);
+    __syncthreads();                       // previous readers of sh are done
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int wv = 0; wv < RS_BLOCK / 64; wv++) tot += sh[wv];
+    return tot;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
+                                                              const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
+                                                              const float* __restrict__ region_size, uint32_t k0, uint32_t k1, uint32_t flags,
+                                                              float4* __restrict__ region_n4, float* __restrict__ inlier_ratio) {
+    __shared__ int sh[RS_BLOCK / 64];
+    const int slot = blockIdx.x;
+    const int rg = region_of_slot[slot];
+    const int n = pts_count[slot];
+    const float* __restrict__ pts = pts_all + 3 * (size_t)pts_start[slot];
+    double a = 0, b = 0, c = 1, d = -1;
+    int maximum = 0;
+    if (n > 0) {
+        // `float depth_abs = 0.0003 * sqrtf(size / 20)` main.cpp:1551-1552
+        float depth_abs_f = (float)(0.0003 * (double)sqrtf(region_size[rg] / 20));
+        double depth_abs = depth_abs_f;
+        for (int k = 0; k < 10000; k++) {                                   // main.cpp:1603-1662
+            uint32_t r[4];
+            philox_raw((uint32_t)k, 0x52414E53u, (uint32_t)rg, k0, k1, r);
+            const float* p1 = pts + 3 * rnd_index(r[0], (uint32_t)n);
+            const float* p2 = pts + 3 * rnd_index(r[1], (uint32_t)n);
+            const float* p3 = pts + 3 * rnd_index(r[2], (uint32_t)n);
+            const double x1 = p1[0], y1 = p1[1], z1 = p1[2], x2 = p2[0], y2 = p2[1], z2 = p2[2], x3 = p3[0], y3 = p3[1], z3 = p3[2];
+            // calcLinePara main.cpp:159: the first component is written with (y3 - y1) twice
+            double ta = (flags & TSAR_FLAG_FIX_PLANE_FIT) ? (y2 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1) : (y3 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1);
+            double tb = (x3 - x1) * (z2 - z1) - (x2 - x1) * (z3 - z1);
+            double tc = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1);
+            double td = -(ta * x1 + tb * y1 + tc * z1);
+            const double sq = sqrt(ta * ta + tb * tb + tc * tc);
+            ta /= sq; tb /= sq; tc /= sq; td /= sq;
+            const int cnt = block_count(pts, n, ta, tb, tc, td, depth_abs, sh);
+            if (cnt >= maximum) { a = ta; b = tb; c = tc; d = td; maximum = cnt; }
+            if (k % 1000 == 0) {                                            // adaptive inlier threshold, main.cpp:1642-1661
+                const double rat = (double)maximum / (double)n;
+                if (rat < 0.3 && depth_abs < 0.003) {
+                    depth_abs_f = (float)((double)depth_abs_f + 0.0001);
+                    depth_abs = depth_abs_f;
+                } else {
+                    const int max2 = block_count(pts, n, a, b, c, d, (double)depth_abs_f + 0.0001, sh);
+                    if ((double)max2 > (double)maximum + (double)n * 0.02) {
+                        depth_abs_f = (float)((double)depth_abs_f + 0.0001);
+                        depth_abs = depth_abs_f;
+                        maximum = max2;
+                    }
+                }
+            }
+        }
+        for (int round = 0; round < 1000; round++) {                        // local perturbation, main.cpp:1667-1711
+            int scn = 0;
+            for (int j = 2000; j >= 2; j /= 10, scn++) {
+                uint32_t r[4];
+                philox_raw((uint32_t)(round * 4 + scn), 0x52414E54u, (uint32_t)rg, k0, k1, r);
+                const int med = j / 2;
+                const double da = (double)((int)rnd_index(r[0], (uint32_t)j) - med) / 10000;
+                const double db = (double)((int)rnd_index(r[1], (uint32_t)j) - med) / 10000;
+                const double dc = (double)((int)rnd_index(r[2], (uint32_t)j) - med) / 10000;
+                const double dd = (double)((int)rnd_index(r[3], (uint32_t)j) - med) / 1000;
+                double ra = a + da, rb = b + db, rc = c + dc, rd = d + dd;
+                const double sq = sqrt(ra * ra + rb * rb + rc * rc);
+                ra /= sq; rb /= sq; rc /= sq; rd /= sq;
+                const int cnt = block_count(pts, n, ra, rb, rc, rd, depth_abs, sh);
+                if (cnt >= maximum) { a = ra; b = rb; c = rc; d = rd; maximum = cnt; }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        region_n4[rg] = make_float4((float)a, (float)b, (float)c, (float)d);
+        inlier_ratio[rg] = n > 0 ? (float)maximum / (float)n : 0.f;
+    }
+}
+
+extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, float* inlier_ratio_out) {
+    if (!ctx) return TSAR_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return TSAR_ERR_HIP; }
+    if (!ctx->have_views || ctx->n_regions < 1) { ctx->err = "tsar_set_views / tsar_set_regions have not been called"; return TSAR_ERR_STATE; }
+    const int nreg = ctx->n_regions;
+    const size_t np = (size_t)ctx->w * ctx->h;
+    hipStream_t st = ctx->stream;
+    std::vector<float> text(nreg);
+    std::vector<int32_t> slot_of_region(nreg, -1), region_of_slot;
+    if (hipMemcpy(text.data(), ctx->region_text, (size_t)nreg * 4, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "D2H failed"; return TSAR_ERR_HIP; }
+    for (int r = 0; r < nreg; r++)
+        if (text[r] == -1.0f) { slot_of_region[r] = (int)region_of_slot.size(); region_of_slot.push_back(r); }
+    const int nslot = (int)region_of_slot.size();
+    std::vector<void*> to_free;
+    auto dmalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; to_free.push_back(p); return p; };
+    auto done = [&](int rc, const char* msg) { if (msg) ctx->err = msg; hipStreamSynchronize(st); for (void* p : to_free) hipFree(p); return rc; };
+    float* d_ratio = (float*)dmalloc((size_t)nreg * 4);
+    if (!d_ratio) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+    hipMemsetAsync(d_ratio, 0, (size_t)nreg * 4, st);
+    if (nslot > 0) {
+        int32_t* d_slot_of_region = (int32_t*)dmalloc((size_t)nreg * 4);
+        int32_t* d_region_of_slot = (int32_t*)dmalloc((size_t)nslot * 4);
+        uint32_t* d_pix = (uint32_t*)dmalloc(np * 4);
+        uint32_t* d_nsel = (uint32_t*)dmalloc(4);
+        int* d_counts = (int*)dmalloc((size_t)nslot * 4);
+        if (!d_slot_of_region || !d_region_of_slot || !d_pix || !d_nsel || !d_counts) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+        hipMemcpyAsync(d_slot_of_region, slot_of_region.data(), (size_t)nreg * 4, hipMemcpyHostToDevice, st);
+        hipMemcpyAsync(d_region_of_slot, region_of_slot.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+        hipMemsetAsync(d_counts, 0, (size_t)nslot * 4, st);
+        // (1) raster-order list of reliable pixels inside textureless regions (main.cpp:1527-1536)
+        ReliableTexturelessPixel pred{ctx->canny, ctx->scale, d_slot_of_region};
+        size_t tmp_bytes = 0;
+        rocprim::counting_iterator<uint32_t> first(0);
+        if (rocprim::select(nullptr, tmp_bytes, first, d_pix, d_nsel, np, pred, st) != hipSuccess) return done(TSAR_ERR_HIP, "rocprim::select sizing failed");
+        void* d_tmp = dmalloc(tmp_bytes);
+        if (!d_tmp) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+        {
+            ScopedKernelTimer tm(ctx, "ransac_select");
+            if (rocprim::select(d_tmp, tmp_bytes, first, d_pix, d_nsel, np, pred, st) != hipSuccess) return done(TSAR_ERR_HIP, "rocprim::select failed");
+        }
+        uint32_t nsel = 0;
+        hipMemcpyAsync(&nsel, d_nsel, 4, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "select failed");
+        std::vector<int> counts(nslot, 0), slot_start(nslot, 0), pts_start(nslot, 0), pts_count(nslot, 0);
+        float* d_pts = nullptr;
+        int *d_slot_start = (int*)dmalloc((size_t)nslot * 4), *d_pts_start = (int*)dmalloc((size_t)nslot * 4), *d_pts_count = (int*)dmalloc((size_t)nslot * 4);
+        if (!d_slot_start || !d_pts_start || !d_pts_count) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+        if (nsel > 0) {
+            uint32_t *d_keys = (uint32_t*)dmalloc((size_t)nsel * 4), *d_keys2 = (uint32_t*)dmalloc((size_t)nsel * 4), *d_pix2 = (uint32_t*)dmalloc((size_t)nsel * 4);
+            if (!d_keys || !d_keys2 || !d_pix2) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+            hipLaunchKernelGGL(ransac_keys_kernel, dim3((nsel + 255) / 256), dim3(256), 0, st, d_pix, (int)nsel, ctx->canny, d_slot_of_region, d_keys, d_counts);
+            // (2) stable sort by region keeps raster order inside each region
+            int bits = 1;
+            while ((1 << bits) < nslot) bits++;
+            size_t sort_bytes = 0;
+            if (rocprim::radix_sort_pairs(nullptr, sort_bytes, d_keys, d_keys2, d_pix, d_pix2, nsel, 0, bits, st) != hipSuccess) return done(TSAR_ERR_HIP, "radix sort sizing failed");
+            void* d_sort_tmp = dmalloc(sort_bytes);
+            if (!d_sort_tmp) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+            {
+                ScopedKernelTimer tm(ctx, "ransac_sort");
+                if (rocprim::radix_sort_pairs(d_sort_tmp, sort_bytes, d_keys, d_keys2, d_pix, d_pix2, nsel, 0, bits, st) != hipSuccess) return done(TSAR_ERR_HIP, "radix sort failed");
+            }
+            hipMemcpyAsync(counts.data(), d_counts, (size_t)nslot * 4, hipMemcpyDeviceToHost, st);
+            if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "sort failed");
+            int acc = 0, pacc = 0;
+            for (int s = 0; s < nslot; s++) {
+                slot_start[s] = acc; acc += counts[s];
+                pts_count[s] = counts[s] > 50000 ? RS_MAXPTS : counts[s];      // main.cpp:1540-1549
+                pts_start[s] = pacc; pacc += pts_count[s];
+            }
+            d_pts = (float*)dmalloc((size_t)(pacc > 0 ? pacc : 1) * 12);
+            if (!d_pts) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+            hipMemcpyAsync(d_slot_start, slot_start.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(d_counts, counts.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(d_pts_start, pts_start.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+            {
+                ScopedKernelTimer tm(ctx, "ransac_points");
+                hipLaunchKernelGGL(ransac_points_kernel, dim3((nsel + 255) / 256), dim3(256), 0, st, ctx->dscene, d_pix2, d_keys2, (int)nsel, ctx->depth, d_slot_start,
+                                   d_counts, d_pts_start, d_pts);
+            }
+        } else {
+            d_pts = (float*)dmalloc(12);
+            hipMemcpyAsync(d_pts_start, pts_start.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+        }
+        hipMemcpyAsync(d_pts_count, pts_count.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+        {
+            ScopedKernelTimer tm(ctx, "ransac_fit");
+            hipLaunchKernelGGL(ransac_fit_kernel, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->region_size,
+                               ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, ctx->region_n4, d_ratio);
+        }
+        if (hipGetLastError() != hipSuccess) return done(TSAR_ERR_HIP, "ransac launch failed");
+    }
+    if (region_planes_out) hipMemcpyAsync(region_planes_out, ctx->region_n4, (size_t)nreg * 16, hipMemcpyDeviceToHost, st);
+    if (inlier_ratio_out) hipMemcpyAsync(inlier_ratio_out, d_ratio, (size_t)nreg * 4, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "ransac kernel failed");
+    return done(TSAR_OK, nullptr);
+}
