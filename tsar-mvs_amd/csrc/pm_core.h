@@ -20,6 +20,12 @@
 #define PM_BLOCK 256
 #define PM_RW 32  // region width in pixels (all kernels)
 
+// Image pointers come out of the DevScene table in memory, so the compiler only knows them as generic
+// ("flat") pointers; flat loads count on both vmcnt and lgkmcnt and serialise against the LDS reads of
+// the tap loop.  They are HBM pointers by construction: say so, and the gathers become global_load.
+typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
+typedef const float __attribute__((address_space(1)))* global_f32_ptr;
+
 template <bool QUAD>
 DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u, float v) {
     // tex2D(tex, u + .5, v + .5), linear filter, clamp addressing (main.cpp:1215-1219).
@@ -30,7 +36,9 @@ DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u
     const int iu = (int)fu, iv = (int)fv;
     float t00, t10, t01, t11;
     if (QUAD) {
-        const uint32_t q = vw.quad[(uint32_t)(__mul24(iv + 1, qpitch) + iu + 1)];
+        // byte offset kept in 32 bits (a view is < 4 GiB) so the gather is `global_load_dword v, v_off, s[base]`
+        const uint32_t off = (uint32_t)(__mul24(iv + 1, qpitch) + iu + 1) * 4u;
+        const uint32_t q = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
         t00 = (float)(q & 0xffu);
         t10 = (float)((q >> 8) & 0xffu);
         t01 = (float)((q >> 16) & 0xffu);
@@ -38,8 +46,8 @@ DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u
     } else {
         const int x0 = min(max(iu, 0), w - 1), x1 = min(max(iu + 1, 0), w - 1);
         const int y0 = min(max(iv, 0), h - 1), y1 = min(max(iv + 1, 0), h - 1);
-        const float* r0 = vw.img + (size_t)y0 * w;
-        const float* r1 = vw.img + (size_t)y1 * w;
+        const global_f32_ptr r0 = (global_f32_ptr)vw.img + (size_t)y0 * w;
+        const global_f32_ptr r1 = (global_f32_ptr)vw.img + (size_t)y1 * w;
         t00 = r0[x0]; t10 = r0[x1]; t01 = r1[x0]; t11 = r1[x1];
     }
     const float top = fma_(ax, t10 - t00, t00);
@@ -56,31 +64,40 @@ struct PixelRef {
 };
 
 // Stage the reference window of this workgroup's region in LDS.  tile is (RW + 2hr) x (RH + 2vr).
-template <int RH>
-DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, float* tile, int x0, int y0, int hr, int vr) {
+// Reference-window texel type: 8-bit imagery (QUAD path) keeps the window as bytes, which is what lets
+// four 256-thread workgroups (weights 36 KiB + window 1 KiB each) share one CU's 160 KiB of LDS.
+template <bool QUAD> struct TileOf { typedef float type; };
+template <> struct TileOf<true> { typedef unsigned char type; };
+template <bool QUAD>
+__host__ __device__ constexpr size_t tile_bytes(int tw, int th) {
+    return ((size_t)tw * th * sizeof(typename TileOf<QUAD>::type) + 15) & ~(size_t)15;
+}
+
+template <int RH, typename TileT>
+DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, TileT* tile, int x0, int y0, int hr, int vr) {
     const int tw = PM_RW + 2 * hr, th = RH + 2 * vr;
-    const float* __restrict__ img = sc->view[0].img;
+    const global_f32_ptr img = (global_f32_ptr)sc->view[0].img;
     const int w = sc->w, h = sc->h;
     for (int k = threadIdx.x; k < tw * th; k += PM_BLOCK) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = min(max(x0 + tx - hr, 0), w - 1), gy = min(max(y0 + ty - vr, 0), h - 1);
-        tile[k] = img[(size_t)gy * w + gx];
+        tile[k] = (TileT)img[(size_t)gy * w + gx];
     }
 }
 
 // Bilateral weights + reference moments (gipuma.cu:247-277, the parts that depend on the reference
 // image only).  own = index of this thread's pixel in the tile, wts = LDS weight column of this thread.
-template <int HR>
-DEVFN PixelRef hoist_reference(const float* tile, int tw, int own, float* wts, int hr_rt, int vr_rt) {
+template <int HR, typename TileT>
+DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, int hr_rt, int vr_rt) {
     const int hr = HR > 0 ? HR : hr_rt, vr = HR > 0 ? HR : vr_rt;
-    const float cen = tile[own];
+    const float cen = (float)tile[own];
     float sum_ref = 0.f, sum_ref_ref = 0.f, wsum = 0.f;
     int tap = 0;
 #pragma unroll
     for (int i = -hr; i <= hr; i += 2) {
 #pragma unroll
         for (int j = -vr; j <= vr; j += 2) {
-            const float r = tile[own + j * tw + i];
+            const float r = (float)tile[own + j * tw + i];
             const float sd = sqrtf((float)(i * i + j * j));
             const float cd = fabsf(r - cen);
             const float wt = tsar_expf(-sd / 50.0f - cd / 18.0f);   // sigma_spatial 5, sigma_color 3 (gipuma.cu:248-249,268)
@@ -103,8 +120,12 @@ DEVFN PixelRef hoist_reference(const float* tile, int tw, int own, float* wts, i
 }
 
 // pmCost gipuma.cu:229-298 for one source view, given the hoisted reference terms.
-template <int HR, bool STRICT, bool QUAD>
-DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const float* tile, int tw, int own, const float* wts,
+// V selects a code-generation variant of the tap loop (identical arithmetic unless noted):
+//   bit 0: two tap columns per trip (12 gathers in flight per wave instead of 6)
+//   bit 1: fast mode only — clamp with v_med3_f32 and take the fraction with v_fract_f32
+//          (differs from floor/subtract only for u in (-2^-24, 0), where fract saturates below 1)
+template <int HR, bool STRICT, bool QUAD, int V = 0>
+DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
                       const PixelRef& pr, int x, int y, const float4& n4) {
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
@@ -112,8 +133,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     plane_homography(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     int tap = 0;
-#pragma unroll
-    for (int i = -hr; i <= hr; i += 2) {
+    auto column = [&](int i) {
         const float xi = (float)(x + i);
         const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
 #pragma unroll
@@ -129,8 +149,22 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 u = X * rz;
                 v = Y * rz;
             }
-            const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
-            const float r = tile[own + j * tw + i];
+            float s;
+            if (QUAD && !STRICT && (V & 2)) {
+                u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
+                v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+                const float ax = __builtin_amdgcn_fractf(u), ay = __builtin_amdgcn_fractf(v);
+                const int iu = (int)floorf(u), iv = (int)floorf(v);
+                const uint32_t off = (uint32_t)(__mul24(iv + 1, qp) + iu + 1) * 4u;
+                const uint32_t q = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
+                const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu), t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
+                const float top = fma_(ax, t10 - t00, t00);
+                const float bot = fma_(ax, t11 - t01, t01);
+                s = fma_(ay, bot - top, top);
+            } else {
+                s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
+            }
+            const float r = (float)tile[own + j * tw + i];
             const float wt = wts[tap * PM_BLOCK];
             const float wr = wt * r, ws = wt * s;
             sum_src += ws;
@@ -138,6 +172,16 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             sum_ref_src = fma_(wr, s, sum_ref_src);
             ++tap;
         }
+    };
+    if ((V & 1) && HR == 5) {
+#pragma unroll 1
+        for (int i = -5; i <= 5; i += 4) {
+            column(i);
+            column(i + 2);
+        }
+    } else {
+#pragma unroll 1
+        for (int i = -hr; i <= hr; i += 2) column(i);
     }
     sum_src *= pr.inv_wsum;
     sum_src_src *= pr.inv_wsum;
@@ -151,8 +195,8 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
 
 // pmCostMultiview_cu gipuma.cu:455-518: best-N combination over the selected views.  The NB
 // smallest costs are kept sorted in registers (sort_small :425-434 sorts all of them).
-template <int NB, int HR, bool STRICT, bool QUAD>
-DEVFN float multiview_cost(const DevScene* __restrict__ sc, const float* tile, int tw, int own, const float* wts, const PixelRef& pr,
+template <int NB, int HR, bool STRICT, bool QUAD, int V = 0>
+DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts, const PixelRef& pr,
                            int x, int y, const float4& n4, int& beview, float& ratio) {
     float best[NB];
 #pragma unroll
@@ -162,7 +206,7 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const float* tile, i
     float cmin = __builtin_inff();
     for (int i = 0; i < num; i++) {
         const int vi = sc->sel[i];
-        float c = view_cost<HR, STRICT, QUAD>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        float c = view_cost<HR, STRICT, QUAD, V>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;
         if (c <= cmin) { cmin = c; bv = vi; }   // last view attaining the minimum (gipuma.cu:506-510)
         float v = c;

@@ -4,21 +4,21 @@
 #include "pm_core.h"
 
 #define FULL_RH 8
-size_t pm_lds_bytes(int hr, int vr, int region_h);
 
 template <int NB, int HR, bool STRICT, bool QUAD, bool INIT>
 __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __restrict__ sc, const float4* __restrict__ planes_in,
                                                            float* __restrict__ c_out, float4* __restrict__ n_out,
                                                            int32_t* __restrict__ beview_out, float* __restrict__ ratio_out, int tiles_x,
                                                            int n_tiles) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef typename TileOf<QUAD>::type TileT;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int tw = PM_RW + 2 * hr, th = FULL_RH + 2 * vr;
-    float* tile = lds;
-    float* wts = lds + tw * th + threadIdx.x;
+    TileT* tile = (TileT*)lds_raw;
+    float* wts = (float*)(lds_raw + tile_bytes<QUAD>(tw, th)) + threadIdx.x;
     const int t = xcd_tile(blockIdx.x, n_tiles);
     const int ty0 = (t / tiles_x) * FULL_RH, tx0 = (t % tiles_x) * PM_RW;
-    stage_ref_tile<FULL_RH>(sc, tile, tx0, ty0, hr, vr);
+    stage_ref_tile<FULL_RH, TileT>(sc, tile, tx0, ty0, hr, vr);
     __syncthreads();
     const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
     const int x = tx0 + lx, y = ty0 + ly;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __res
     } else {
         n4 = planes_in[p];
     }
-    const PixelRef pr = hoist_reference<HR>(tile, tw, own, wts, hr, vr);
+    const PixelRef pr = hoist_reference<HR, TileT>(tile, tw, own, wts, hr, vr);
     float cost = TSAR_MAXCOST, rt = 0.f;
     int bv = -1;
     if (pr.textured) cost = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, n4, bv, rt);
@@ -73,7 +73,7 @@ static int launch_full_t(tsar_ctx* ctx, const float4* planes, float* c, float4* 
     const DevScene& hs = ctx->hscene;
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + FULL_RH - 1) / FULL_RH;
     const int n_tiles = tiles_x * tiles_y;
-    const size_t lds = pm_lds_bytes(hs.hrad, hs.vrad, FULL_RH);
+    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, FULL_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK;
     auto kern = pm_full_kernel<NB, HR, STRICT, QUAD, INIT>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {

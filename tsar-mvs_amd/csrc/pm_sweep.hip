@@ -103,22 +103,28 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
     }
 }
 
-template <int NB, int HR, bool STRICT, bool QUAD>
+DEVFN bool same_bits(const float4& a, const float4& b) {
+    return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+           __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
+}
+
+template <int NB, int HR, bool STRICT, bool QUAD, int V = 0>
 __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
                                                             const float* __restrict__ c_same, const float4* __restrict__ n_same,
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
                                                             int32_t* __restrict__ beview_out, uint32_t stream_id, int do_prop,
-                                                            int do_refine, int tiles_x, int n_tiles) {
-    extern __shared__ float lds[];
+                                                            int do_refine, int tiles_x, int n_tiles, int cost_consistent) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef typename TileOf<QUAD>::type TileT;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int tw = PM_RW + 2 * hr, th = SWEEP_RH + 2 * vr;
-    float* tile = lds;
-    float* wts = lds + tw * th + threadIdx.x;
+    TileT* tile = (TileT*)lds_raw;
+    float* wts = (float*)(lds_raw + tile_bytes<QUAD>(tw, th)) + threadIdx.x;
 
     const int t = xcd_tile(blockIdx.x, n_tiles);
     const int ty0 = (t / tiles_x) * SWEEP_RH, tx0 = (t % tiles_x) * PM_RW;
-    stage_ref_tile<SWEEP_RH>(sc, tile, tx0, ty0, hr, vr);
+    stage_ref_tile<SWEEP_RH, TileT>(sc, tile, tx0, ty0, hr, vr);
     __syncthreads();
 
     const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
@@ -132,13 +138,14 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
 
     float cost_now = c_same[p];
     float4 n_now = n_same[p];
-    const PixelRef pr = hoist_reference<HR>(tile, tw, own, wts, hr, vr);
+    const PixelRef pr = hoist_reference<HR, TileT>(tile, tw, own, wts, hr, vr);
     bool wrote = false;
     float ratio_w = 0.f;
     int beview_w = 0;
     if (pr.textured) {
         const DevRef& rf = sc->ref;
         float depth_now = plane_depth(rf, n_now, x, y);
+        const float4 n_first = n_now;
         if (do_prop) {
             Candidate cand[8];
             select_candidates(sc, c_same, c_other, x, y, cand);
@@ -146,12 +153,17 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
             for (int a = 0; a < 8; a++) {
                 if (cand[a].idx < 0) continue;
                 const float4 nb = cand[a].same ? n_same[cand[a].idx] : n_other[cand[a].idx];
+                // A neighbour often carries the very plane this pixel already holds (or held when the launch
+                // started): planes spread by verbatim copies.  While c[p] is the score of norm4[p] (true for
+                // every state produced by init / sweeps) re-scoring it returns a cost that is not smaller
+                // than cost_now, so the reference's `cost_before < *cost_now` (gipuma.cu:555) rejects it.
+                if (cost_consistent && (same_bits(nb, n_now) || same_bits(nb, n_first))) continue;
                 const float depth_b = plane_depth(rf, nb, x, y);
                 // spatialPropagation_cu gipuma.cu:524-566; the range test is done first: a
                 // hypothesis outside [depthMin, depthMax] is never accepted, so it is not scored.
                 if (!(depth_b >= rf.depthMin && depth_b <= rf.depthMax)) continue;
                 int bv; float rt;
-                const float cost_b = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, nb, bv, rt);
+                const float cost_b = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, nb, bv, rt);
                 if (cost_b < cost_now) {
                     cost_now = cost_b; n_now = nb; depth_now = depth_b;
                     ratio_w = rt; beview_w = bv; wrote = true;
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
                 n_t.x = nt[0]; n_t.y = nt[1]; n_t.z = nt[2];
                 n_t.w = plane_offset(rf, nt, x, y, depthOut);
                 int bv; float rt;
-                const float cost_t = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
+                const float cost_t = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
                 if (cost_t < cost_now) {
                     cost_now = cost_t; n_now = n_t; depth_now = depthOut;
                     ratio_w = rt; beview_w = bv; wrote = true;
@@ -199,24 +211,21 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
     if (wrote) { ratio_out[p] = ratio_w; beview_out[p] = beview_w; }
 }
 
-size_t pm_lds_bytes(int hr, int vr, int region_h) {
-    const int taps = (hr + 1) * (vr + 1);
-    return sizeof(float) * ((size_t)(PM_RW + 2 * hr) * (region_h + 2 * vr) + (size_t)taps * PM_BLOCK);
-}
 
-template <int NB, int HR, bool STRICT, bool QUAD>
+template <int NB, int HR, bool STRICT, bool QUAD, int V = 0>
 static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                           uint32_t stream_id, int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
     const int n_tiles = tiles_x * tiles_y;
-    const size_t lds = pm_lds_bytes(hs.hrad, hs.vrad, SWEEP_RH);
-    auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD>;
+    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK;
+    auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD, V>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ScopedKernelTimer tm(ctx, "pm_sweep");
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
-                           other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles);
+                           other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles,
+                           ctx->cost_consistent ? 1 : 0);
     }
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;
@@ -226,12 +235,25 @@ template <int NB, int HR>
 static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
     if (strict) return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
+    if (quad && NB == 2 && HR == 5) {   // the production configuration: code-generation variants (TSAR_VARIANT)
+        switch (ctx->variant) {
+            case 1: return launch_sweep_t<2, 5, false, true, 1>(ctx, colour, a, b, c, sid, dp, dr);
+            case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
+            case 3: return launch_sweep_t<2, 5, false, true, 3>(ctx, colour, a, b, c, sid, dp, dr);
+            default: break;
+        }
+    }
     return quad ? launch_sweep_t<NB, HR, false, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, false, false>(ctx, colour, a, b, c, sid, dp, dr);
 }
 
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                     int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
+    if (ctx->window_sweep) {   // experimental LDS-window form (pm_sweep_win.hip), off by default: see DESIGN.md §4
+        int launched = 0;
+        const int rc = launch_pm_sweep_win(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine, &launched);
+        if (rc != TSAR_OK || launched) return rc;
+    }
     const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;
     const bool r5 = hs.hrad == 5 && hs.vrad == 5;
     if (need <= 2) return r5 ? launch_sweep_nh<2, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)

@@ -1,5 +1,6 @@
 // tsar_api.hip — the C ABI of include/tsar.h: context, device memory, camera algebra, call order.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -173,6 +174,8 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TSAR_ERR_HIP; }
     tsar_default_params(&ctx->params);
+    if (const char* e = getenv("TSAR_WINDOW_SWEEP")) ctx->window_sweep = e[0] == '1';
+    if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
     *out = ctx;
     return TSAR_OK;
 }
@@ -327,6 +330,7 @@ extern "C" int tsar_pm_init(tsar_ctx* ctx) {
     ctx->have_state = true;
     ctx->have_out = false;
     ctx->sweeps_done = 0;
+    ctx->cost_consistent = true;
     return TSAR_OK;
 }
 
@@ -429,6 +433,7 @@ extern "C" int tsar_set_plane(tsar_ctx* ctx, const float* planes, const float* c
     TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[0].n4, planes, np * 16, in_kind(mem), ctx->stream));
     TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->buf[0].c, cost, np * 4, in_kind(mem), ctx->stream));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cost_consistent = false;
     ctx->have_state = true;
     ctx->have_out = false;
     return TSAR_OK;
@@ -473,6 +478,7 @@ extern "C" int tsar_load_planes(tsar_ctx* ctx, const float* depth, const float* 
     TRY(d.rc); TRY(n.rc);
     TRY(launch_get_disp(ctx, d.d, n.d));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cost_consistent = false;
     ctx->have_state = true;
     ctx->have_out = false;
     return TSAR_OK;
@@ -492,6 +498,7 @@ extern "C" int tsar_compute_disp_final(tsar_ctx* ctx, const float* resize_planes
     const size_t np = (size_t)ctx->w * ctx->h;
     TmpIn<float> r(ctx, resize_planes, 4 * np, mem), t(ctx, text, np, mem);
     TRY(r.rc); TRY(t.rc);
+    ctx->cost_consistent = false;
     TRY(launch_compute_disp_final(ctx, (const float4*)r.d, t.d));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_out = true;
@@ -500,6 +507,7 @@ extern "C" int tsar_compute_disp_final(tsar_ctx* ctx, const float* resize_planes
 extern "C" int tsar_depth_to_plane(tsar_ctx* ctx) {
     CHECK_CTX(ctx);
     NEED_STATE(ctx);
+    ctx->cost_consistent = false;
     TRY(launch_depth_to_plane(ctx));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSAR_OK;
@@ -592,6 +600,7 @@ extern "C" int tsar_fill_textureless(tsar_ctx* ctx) {   // gipuma_fill gipuma.cu
     CHECK_CTX(ctx);
     NEED_STATE(ctx);
     if (ctx->n_regions < 1) return fail(ctx, TSAR_ERR_STATE, "tsar_set_regions has not been called");
+    ctx->cost_consistent = false;
     TRY(launch_update_scale(ctx));
     TRY(launch_compute_disp(ctx));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

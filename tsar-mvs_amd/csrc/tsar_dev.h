@@ -79,12 +79,15 @@ struct tsar_ctx {
     int32_t *beview = nullptr, *canny = nullptr;
     float4* out4 = nullptr;      // result of compute_disp: (n_world, depth)
     bool have_out = false;
+    bool cost_consistent = false;   // c[p] is the multi-view score of n4[p] for every pixel (init / sweep produced the state)
     // regions (cannylines)
     int n_regions = 0;
     float *region_text = nullptr, *region_size = nullptr;
     float4* region_n4 = nullptr;
     int sweeps_done = 0;         // RNG stream counter
     // timing
+    bool window_sweep = false;   // TSAR_WINDOW_SWEEP=1: LDS-window form of the sweep (pm_sweep_win.hip), experimental
+    int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); 2 measured fastest
     bool timing = false;
     std::vector<KernelTimer> timers;
 };
@@ -112,6 +115,8 @@ int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, in
 int launch_pm_init(tsar_ctx* ctx);
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                     uint32_t stream_id, int do_prop, int do_refine);
+int launch_pm_sweep_win(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
+                        int do_prop, int do_refine, int* launched);
 int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio);
 int launch_get_disp(tsar_ctx* ctx, const float* depth_in, const float* normal_world);
 int launch_compute_disp(tsar_ctx* ctx);

@@ -187,5 +187,6 @@ extern "C" int tsar_wmf(tsar_ctx* ctx, int iters, int final_pass) {
     hipFree(scale_snap);
     hipFree(depth_snap);
     ctx->have_out = false;
+    if (final_pass) ctx->cost_consistent = false;
     return rc;
 }
