@@ -30,6 +30,31 @@ def alg_bytes_per_pixel_iteration(n_src: int) -> int:
     return 136 + 16 * (1 + n_src)
 
 
+def traffic_from_profiles():
+    """HBM bytes per pm_sweep launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of this same command, profiles/r*/pmc_{fetch,write}_size_sweep.csv; bench.py cannot
+    read hardware counters itself).  FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md §HBM prescribes for gfx950 (it tallies 128-B requests at 64 B) — uncalibrated for
+    this kernel's 4-byte gathers, so read it as an upper bound.  Converged launches only (the first two of a run
+    start from random planes).  Returns None when no profile is committed."""
+    import csv
+    import glob
+    prof = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r*")) if os.path.isdir(d))
+    if not prof:
+        return None
+    vals = {}
+    for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = os.path.join(prof[-1], f"pmc_{name}_size_sweep.csv")
+        if not os.path.exists(f):
+            return None
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "pm_sweep" in r["Kernel_Name"]]
+        rows = rows[2:] if len(rows) > 2 else rows
+        if not rows:
+            return None
+        vals[name] = sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0
+    return 2.0 * vals["fetch"] + vals["write"]
+
+
 def cpu_baseline(args):
     """The CPU oracle (kind "port": the reference has no CPU path) on a bounded sample of the same
     workload: same view count / window / iterations, smaller image."""
@@ -144,10 +169,10 @@ def main():
             avg_ms = total_ms / launches
             bytes_per_launch = alg_bytes_per_pixel_iteration(args.views) * (w * h / 2.0)   # one launch = one colour = W*H/2 pixel-iterations
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic_from_profiles(),
                                 "kernel": "pm_sweep_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                                "note": "the kernel is FP32-VALU/gather bound (SURVEY 8d: ~970 flop/B); HBM fraction is reported because the metric asks for it"}
+                                "note": "vector-L1 (TCP) access-rate bound, then FP32 VALU (SURVEY 8d: ~970 flop/B; profiles/r01/README.md); the HBM fraction is reported because the metric asks for it. traffic = committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, converged launches), null if absent"}
             line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -1,0 +1,95 @@
+"""Row N1: the reference's file formats (cams/%08d_cam.txt, pair.txt, .dmb) and the C++ CLI that keeps
+its command line."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from tsar_mvs_amd import io as tio
+from tsar_mvs_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "tsar-mvs_amd", "tsar_gipuma")
+
+
+def test_dmb_layout_is_the_reference_layout(tmp_path):
+    """int32 type=1, h, w, channels, then float32 row-major (reference fileIoUtils.h:333-381)"""
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    p = str(tmp_path / "d.dmb")
+    tio.write_dmb(p, a)
+    raw = open(p, "rb").read()
+    assert struct.unpack("<iiii", raw[:16]) == (1, 2, 3, 1)
+    assert np.array_equal(np.frombuffer(raw[16:], "<f4"), a.ravel())
+    assert np.array_equal(tio.read_dmb(p), a)
+    n = np.random.default_rng(0).normal(size=(4, 5, 3)).astype(np.float32)
+    tio.write_dmb(p, n)
+    assert struct.unpack("<iiii", open(p, "rb").read(16)) == (1, 4, 5, 3)
+    assert np.array_equal(tio.read_dmb(p), n)
+    open(p, "wb").write(struct.pack("<iiii", 2, 1, 1, 1) + b"\0" * 4)
+    with pytest.raises(ValueError):
+        tio.read_dmb(p)            # the reference only supports float (type 1)
+
+
+def test_cam_and_pair_files_round_trip(tmp_path):
+    sc = synth.make_scene(64, 48, 3, seed=2)
+    root = str(tmp_path)
+    tio.export_scene(sc, root)
+    for k in range(4):
+        K, R, t, dmin, dmax = tio.read_cam(os.path.join(root, "cams", f"{k:08d}_cam.txt"))
+        assert np.allclose(K, sc.K[k]) and np.allclose(R, sc.R[k]) and np.allclose(t, sc.t[k])
+        assert abs(dmin - sc.depth_min) < 1e-6 and abs(dmax - sc.depth_max) < 1e-6
+        img = tio.read_pgm(os.path.join(root, "images", f"{k:08d}.pgm"))
+        assert np.array_equal(img, sc.images[k].numpy())
+    pairs = tio.read_pairs(os.path.join(root, "pair.txt"))
+    assert sorted(pairs) == [0, 1, 2, 3] and [s for s, _ in pairs[1]] == [0, 2, 3]
+    # slot of a source view in the reference's argv list: id if id > ref else id + 1 (main.cpp:1371-1375)
+    assert tio.source_slots(1, [0, 2, 3]) == [1, 2, 3]
+    assert tio.source_slots(0, [1, 2, 3]) == [1, 2, 3]
+    assert tio.source_slots(3, [0, 1, 2]) == [1, 2, 3]
+
+
+def test_cli_builds_and_keeps_the_reference_flags():
+    import __graft_entry__ as ge
+    if not os.path.exists(CLI):
+        ge.build()
+    out = subprocess.run([CLI, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "-mslp_folder" in out.stdout and "--blocksize" in out.stdout
+    bad = subprocess.run([CLI, "a.pgm", "b.pgm", "-mslp_folder", "x/", "-images_folder", "y/", "--blocksize=10"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "positive odd number" in bad.stdout       # main.cpp:823-831
+    warn = subprocess.run([CLI, "--frobnicate", "--help"], capture_output=True, text=True)
+    assert "unknown option --frobnicate" in warn.stdout                       # unknown flags only warn (main.cpp:941-944)
+
+
+@pytest.mark.gpu
+def test_cli_matches_the_library(tmp_path):
+    """the per-view command line of the reference's shell loop (scripts/courtyard.sh:44) end to end"""
+    from tsar_mvs_amd import api
+    sc = synth.make_scene(128, 96, 3, seed=5)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    names = [f"{k:08d}.pgm" for k in (1, 0, 2, 3)]          # reference view 1 first, then every other image
+    cmd = [CLI, *names, "-mslp_folder", root, "-images_folder", root + "images/", "-krt_file", "unused", "-output_folder", root + "out/",
+           "-no_display", "--cam_scale=1", "--iterations=2", "--blocksize=11", "--cost_gamma=10", "--cost_comb=best_n", "--n_best=1", "--seed=7"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    depth = tio.read_dmb(root + "APD/00000001/TSAR_disp.dmb")
+    normal = tio.read_dmb(root + "APD/00000001/TSAR_normals.dmb")
+    assert depth.shape == (96, 128) and normal.shape == (96, 128, 3)
+    order = [1, 0, 2, 3]
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=7 + 1))
+    m.set_views([sc.images[k] for k in order], sc.K[order], sc.R[order], sc.t[order])
+    m.set_view_subset(tio.source_slots(1, [0, 2, 3]))
+    m.pm_init()
+    m.pm_iterate(2)
+    m.compute_disp()
+    res = m.get_result()
+    assert np.array_equal(depth, res["depth"]) and np.array_equal(normal, res["normal"])
+    m.close()
+    # --all: every view of pair.txt, one thread per GPU
+    out = subprocess.run([CLI, "--all", "--gpus=1", "-mslp_folder", root, "-images_folder", root + "images/", "--iterations=1", "--blocksize=11", "--n_best=1"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert all(os.path.exists(root + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(4))

@@ -1,0 +1,304 @@
+// tsar_gipuma — C++ host driver above the C ABI (include/tsar.h), keeping the reference's
+// process-level contract (reference main.cpp:708-1009 flags, :1351-1376 pair.txt,
+// fileIoUtils.h:111-163 cam files, :333-381 .dmb) so that the per-view shell loop
+// (reference scripts/courtyard.sh:29-48) and the fuser (x/1.sh:30) keep working:
+//
+//   tsar_gipuma <ref.pgm> <src.pgm...> -images_folder D/images/ -mslp_folder D/ -krt_file X
+//               -output_folder O --cam_scale=1 --iterations=8 --blocksize=11 --cost_comb=best_n --n_best=1
+//
+// writes D/APD/<id>/TSAR_disp.dmb (depth) and TSAR_normals.dmb (world normals), the two files
+// Fusion reads.  Beyond the reference:
+//   --all [--gpus=N]   process every reference view of pair.txt, dealt round-robin to N GPUs, one host
+//                      thread + one tsar_ctx per GPU (replaces the shell loop)
+//   --mode=patchmatch  (default) random init + iterations; --mode=load starts from
+//                      APD/<id>/depths_geom.dmb + normals.dmb like the reference snapshot (main.cpp:1462-1490)
+//   --seed=S, --strict, --fix-quirks
+// Images: binary PGM (the image has no JPEG decoder; `python -m tsar_mvs_amd.io convert a.jpg a.pgm`).
+// A name ending in .jpg/.png is looked up as the same stem + .pgm.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tsar.h"
+
+struct Options {
+    std::vector<std::string> images;
+    std::string images_folder, mslp_folder, krt_file, output_folder;
+    int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
+    float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
+    bool all = false, strict = false, fix_quirks = false;
+    int gpus = 1;
+    uint64_t seed = 0;
+    std::string mode = "patchmatch";
+};
+
+struct CamFile {
+    tsar_camera cam;
+    float depth_min, depth_max;
+};
+
+static bool read_cam(const std::string& path, CamFile& out) {   // fileIoUtils.h:117-153
+    std::ifstream f(path);
+    if (!f) return false;
+    std::string word;
+    f >> word;   // "extrinsic"
+    for (int r = 0; r < 3; r++) f >> out.cam.R[3 * r] >> out.cam.R[3 * r + 1] >> out.cam.R[3 * r + 2] >> out.cam.t[r];
+    float tmp;
+    f >> tmp >> tmp >> tmp >> tmp;
+    f >> word;   // "intrinsic"
+    for (int r = 0; r < 3; r++) f >> out.cam.K[3 * r] >> out.cam.K[3 * r + 1] >> out.cam.K[3 * r + 2];
+    float interval, num;
+    f >> out.depth_min >> interval >> num >> out.depth_max;
+    return !f.fail();
+}
+
+static bool read_pairs(const std::string& path, std::map<int, std::vector<int>>& pairs) {   // main.cpp:1351-1376
+    std::ifstream f(path);
+    if (!f) return false;
+    int n = 0;
+    f >> n;
+    for (int i = 0; i < n; i++) {
+        int ref, k;
+        f >> ref >> k;
+        std::vector<int> src(k);
+        for (int j = 0; j < k; j++) { float score; f >> src[j] >> score; }
+        if (f.fail()) return false;
+        pairs[ref] = src;
+    }
+    return true;
+}
+
+static bool read_pgm(const std::string& path, std::vector<float>& img, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int maxv = 0, got = 0, vals[3];
+    if (fscanf(f, "%2s", magic) != 1 || strcmp(magic, "P5") != 0) { fclose(f); return false; }
+    while (got < 3) {
+        int c = fgetc(f);
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (c == EOF) { fclose(f); return false; }
+        if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+        ungetc(c, f);
+        if (fscanf(f, "%d", &vals[got]) != 1) { fclose(f); return false; }
+        got++;
+    }
+    fgetc(f);   // single whitespace after maxval
+    w = vals[0]; h = vals[1]; maxv = vals[2];
+    if (maxv > 255 || w <= 0 || h <= 0) { fclose(f); return false; }
+    std::vector<unsigned char> raw((size_t)w * h);
+    const bool ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+    fclose(f);
+    if (!ok) return false;
+    img.resize(raw.size());
+    for (size_t i = 0; i < raw.size(); i++) img[i] = (float)raw[i];   // convertTo(CV_32FC1), main.cpp:1423
+    return true;
+}
+
+static bool write_dmb(const std::string& path, const float* data, int h, int w, int nb) {   // fileIoUtils.h:333-381
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "Error opening file %s\n", path.c_str()); return false; }
+    const int32_t hdr[4] = {1, h, w, nb};
+    bool ok = fwrite(hdr, sizeof(int32_t), 4, f) == 4;
+    ok = ok && fwrite(data, sizeof(float), (size_t)h * w * nb, f) == (size_t)h * w * nb;
+    fclose(f);
+    return ok;
+}
+static bool read_dmb(const std::string& path, std::vector<float>& data, int& h, int& w, int& nb) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    int32_t hdr[4];
+    if (fread(hdr, sizeof(int32_t), 4, f) != 4 || hdr[0] != 1) { fclose(f); return false; }
+    h = hdr[1]; w = hdr[2]; nb = hdr[3];
+    data.resize((size_t)h * w * nb);
+    const bool ok = fread(data.data(), sizeof(float), data.size(), f) == data.size();
+    fclose(f);
+    return ok;
+}
+
+static std::string stem8(const std::string& name) { return name.substr(0, 8); }   // main.cpp:1460
+static std::string pgm_name(const std::string& name) {
+    const size_t dot = name.find_last_of('.');
+    const std::string ext = dot == std::string::npos ? "" : name.substr(dot);
+    return (ext == ".pgm") ? name : name.substr(0, dot) + ".pgm";
+}
+static void mkdirs(const std::string& path) {
+    std::string cur;
+    for (size_t i = 0; i < path.size(); i++) {
+        cur += path[i];
+        if (path[i] == '/' || i + 1 == path.size()) mkdir(cur.c_str(), 0777);
+    }
+}
+
+static void usage() {
+    printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
+           "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n] [--n_best=N] [--cam_scale=S]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load] [--seed=S] [--strict] [--fix-quirks]\n"
+           "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
+}
+
+static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946: same spellings, unknown options only warn
+    for (int i = 1; i < argc; i++) {
+        const char* a = argv[i];
+        auto starts = [&](const char* p) { return strncmp(a, p, strlen(p)) == 0; };
+        if (a[0] != '-') o.images.push_back(a);
+        else if (starts("--iterations=")) o.iterations = atoi(a + 13);
+        else if (starts("--blocksize=")) {
+            const int k = atoi(a + 12);
+            if (k < 1 || k % 2 != 1) { printf("Command-line parameter error: The block size (--blocksize=<...>) must be a positive odd number\n"); return -1; }
+            o.blocksize = k;
+        } else if (starts("--n_best=")) o.n_best = atoi(a + 9);
+        else if (starts("--cost_comb=")) {
+            const char* v = a + 12;
+            if (!strcmp(v, "all")) o.cost_comb = TSAR_COMB_ALL;
+            else if (!strcmp(v, "best_n")) o.cost_comb = TSAR_COMB_BEST_N;
+            else { printf("Command-line parameter error: Unknown cost combination method\n\n"); usage(); return -1; }   // angle/good: not on the GPU path
+        } else if (starts("--cam_scale=")) o.cam_scale = (float)atof(a + 12);
+        else if (starts("--depth_min=")) o.depth_min = (float)atof(a + 12);
+        else if (starts("--depth_max=")) o.depth_max = (float)atof(a + 12);
+        else if (starts("--gpus=")) o.gpus = atoi(a + 7);
+        else if (starts("--seed=")) o.seed = strtoull(a + 7, nullptr, 10);
+        else if (starts("--mode=")) o.mode = a + 7;
+        else if (!strcmp(a, "--all")) o.all = true;
+        else if (!strcmp(a, "--strict")) o.strict = true;
+        else if (!strcmp(a, "--fix-quirks")) o.fix_quirks = true;
+        else if (!strcmp(a, "-images_folder") && i + 1 < argc) o.images_folder = argv[++i];
+        else if (!strcmp(a, "-mslp_folder") && i + 1 < argc) o.mslp_folder = argv[++i];
+        else if (!strcmp(a, "-krt_file") && i + 1 < argc) o.krt_file = argv[++i];
+        else if (!strcmp(a, "-output_folder") && i + 1 < argc) o.output_folder = argv[++i];
+        else if (!strcmp(a, "-no_display") || starts("--cost_gamma=") || starts("--min_angle=") || starts("--max_angle=") || starts("--cost_tau_color=") ||
+                 starts("--cost_tau_gradient=") || starts("--cost_alpha=") || starts("--max_views=") || starts("--num_img_processed=")) {
+            // accepted for script compatibility; these feed cost functions / view selection the GPU path does not use
+        } else if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(); return 1; }
+        else printf("Command-line parameter warning: unknown option %s\n", a);
+    }
+    return 0;
+}
+
+// one reference view: images[0] is the reference, the rest the candidate sources in argv order
+static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int n = (int)names.size();
+    std::vector<std::vector<float>> gray(n);
+    std::vector<const float*> ptrs(n);
+    std::vector<tsar_camera> cams(n);
+    int w = 0, h = 0;
+    float dmin = o.depth_min, dmax = o.depth_max;
+    for (int i = 0; i < n; i++) {
+        int wi, hi;
+        const std::string ip = o.images_folder + pgm_name(names[i]);
+        if (!read_pgm(ip, gray[i], wi, hi)) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); return -1; }
+        if (i == 0) { w = wi; h = hi; }
+        if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); return -1; }
+        ptrs[i] = gray[i].data();
+        CamFile cf;
+        const std::string cp = o.mslp_folder + "cams/" + stem8(names[i]) + "_cam.txt";
+        if (!read_cam(cp, cf)) { fprintf(stderr, "cannot read camera %s\n", cp.c_str()); return -1; }
+        cams[i] = cf.cam;
+        if (i == 0) {   // depth range of the reference view (fileIoUtils.h:150-153) unless given on the command line
+            if (dmin <= 0) dmin = cf.depth_min;
+            if (dmax <= 0) dmax = cf.depth_max;
+        }
+    }
+    tsar_ctx* ctx = nullptr;
+    int rc = tsar_create(device, &ctx);
+    if (rc != TSAR_OK) { fprintf(stderr, "tsar_create(device %d) failed: %d\n", device, rc); return rc; }
+    auto fail = [&](const char* what) { fprintf(stderr, "%s: %s\n", what, tsar_last_error(ctx)); tsar_destroy(ctx); return -1; };
+    tsar_params p;
+    tsar_default_params(&p);
+    p.box_hsize = p.box_vsize = o.blocksize;
+    p.n_best = o.n_best; p.cost_comb = o.cost_comb; p.cam_scale = o.cam_scale;
+    p.depth_min = dmin; p.depth_max = dmax;
+    p.seed = o.seed + (uint64_t)ref_id;
+    p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0);
+    if (tsar_set_params(ctx, &p) != TSAR_OK) return fail("tsar_set_params");
+    if (tsar_set_views(ctx, n, w, h, ptrs.data(), TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
+    if (!subset_slots.empty()) {
+        std::vector<int32_t> s(subset_slots.begin(), subset_slots.end());
+        if (tsar_set_view_subset(ctx, (int)s.size(), s.data()) != TSAR_OK) return fail("tsar_set_view_subset");
+    }
+    const std::string out_dir = o.mslp_folder + "APD/" + stem8(names[0]) + "/";   // main.cpp:1462, 1813-1830
+    mkdirs(out_dir);
+    const size_t np = (size_t)w * h;
+    if (o.mode == "load") {
+        std::vector<float> d, nrm;
+        int hh, ww, nb;
+        if (!read_dmb(out_dir + "depths_geom.dmb", d, hh, ww, nb) || hh != h || ww != w || nb != 1) { fprintf(stderr, "cannot read %sdepths_geom.dmb\n", out_dir.c_str()); tsar_destroy(ctx); return -1; }
+        if (!read_dmb(out_dir + "normals.dmb", nrm, hh, ww, nb) || hh != h || ww != w || nb != 3) { fprintf(stderr, "cannot read %snormals.dmb\n", out_dir.c_str()); tsar_destroy(ctx); return -1; }
+        if (tsar_load_planes(ctx, d.data(), nrm.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_load_planes");
+    } else {
+        if (tsar_pm_init(ctx) != TSAR_OK) return fail("tsar_pm_init");
+        if (tsar_pm_iterate(ctx, o.iterations) != TSAR_OK) return fail("tsar_pm_iterate");
+    }
+    if (tsar_compute_disp(ctx) != TSAR_OK) return fail("tsar_compute_disp");
+    std::vector<float> depth(np), normal(3 * np);
+    if (tsar_get_result(ctx, depth.data(), normal.data(), nullptr, nullptr, TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_get_result");
+    tsar_destroy(ctx);
+    if (!write_dmb(out_dir + "TSAR_disp.dmb", depth.data(), h, w, 1)) return -1;
+    if (!write_dmb(out_dir + "TSAR_normals.dmb", normal.data(), h, w, 3)) return -1;
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (seconds) *seconds = sec;
+    FILE* rf = fopen((out_dir + "TSAR_results.txt").c_str(), "a");   // main.cpp:1854-1860
+    if (rf) { fprintf(rf, "Total runtime: %g sec ( %g min)\n", sec, sec / 60.0); fclose(rf); }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    Options o;
+    const int pr = parse_args(argc, argv, o);
+    if (pr != 0) return pr < 0 ? 1 : 0;
+    if (o.mslp_folder.empty() || o.images_folder.empty()) { usage(); return 1; }
+    if (o.mslp_folder.back() != '/') o.mslp_folder += '/';
+    if (o.images_folder.back() != '/') o.images_folder += '/';
+    std::map<int, std::vector<int>> pairs;
+    const bool have_pairs = read_pairs(o.mslp_folder + "pair.txt", pairs);
+    if (o.all) {
+        if (!have_pairs) { fprintf(stderr, "--all needs %spair.txt\n", o.mslp_folder.c_str()); return 1; }
+        std::vector<int> refs;
+        for (auto& kv : pairs) refs.push_back(kv.first);
+        const int ngpu = o.gpus < 1 ? 1 : o.gpus;
+        std::vector<int> status(ngpu, 0);
+        std::vector<std::thread> th;
+        for (int g = 0; g < ngpu; g++)
+            th.emplace_back([&, g]() {
+                for (size_t k = g; k < refs.size(); k += ngpu) {   // round-robin: every view of a scene costs the same
+                    const int ref = refs[k];
+                    char buf[32];
+                    std::vector<std::string> names;
+                    snprintf(buf, sizeof buf, "%08d.pgm", ref);
+                    names.push_back(buf);
+                    for (int s : pairs[ref]) { snprintf(buf, sizeof buf, "%08d.pgm", s); names.push_back(buf); }
+                    double sec = 0;
+                    const int rc = run_view(o, g, names, {}, ref, &sec);
+                    printf("view %08d on gpu %d: %s (%.2f s)\n", ref, g, rc == 0 ? "ok" : "FAILED", sec);
+                    if (rc != 0) status[g] = rc;   // a failed view does not stop the others
+                }
+            });
+        for (auto& t : th) t.join();
+        for (int s : status)
+            if (s != 0) return 1;
+        return 0;
+    }
+    if (o.images.size() < 2) { usage(); return 1; }
+    // camera id from the reference image name, source slots from pair.txt (main.cpp:1347-1376)
+    const int camera_id = atoi(o.images[0].substr(4, 8).c_str());
+    std::vector<int> slots;
+    if (have_pairs && pairs.count(camera_id))
+        for (int s : pairs[camera_id]) slots.push_back(s > camera_id ? s : s + 1);
+    for (int s : slots)
+        if (s < 1 || s >= (int)o.images.size()) { fprintf(stderr, "pair.txt refers to view slot %d but only %zu images were given\n", s, o.images.size()); return 1; }
+    double sec = 0;
+    const int rc = run_view(o, 0, o.images, slots, camera_id, &sec);
+    printf("Total runtime including disk i/o: %gsec\n", sec);
+    return rc == 0 ? 0 : 1;
+}
