@@ -297,3 +297,77 @@ def test_textureless_fill(small_scene):
     assert (o.c[:, w // 2:] == 0).all() and (o.scale[:, w // 2:] == 1).all()
     c0 = o.camera(0)
     assert np.allclose(c0.f / o.depth[:, w // 2:], 6.0, rtol=1e-5)
+
+
+# ---- TSAR refinement / SLIC oracle parts --------------------------------------------------------------
+def test_cube_root_and_cielab_known_values():
+    xs = np.linspace(0.009, 1.2, 500, dtype=np.float32)
+    got = np.array([ol.cbrtf(float(x)) for x in xs], np.float32)
+    ref = np.cbrt(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / np.spacing(ref.astype(np.float32))) <= 2.0
+    white = ol.rgb2lab([255, 255, 255, 0])
+    assert abs(white[0] - 100.0) < 0.01 and abs(white[1]) < 0.01 and abs(white[2]) < 0.01
+    black = ol.rgb2lab([0, 0, 0, 0])
+    assert abs(black[0]) < 1e-4
+    red = ol.rgb2lab([0, 0, 255, 0])           # b, g, r order (gSLICr_seg_engine_shared.h:21-23)
+    assert abs(red[0] - 53.24) < 0.05 and abs(red[1] - 80.09) < 0.1 and abs(red[2] - 67.20) < 0.1
+
+
+def test_slic_on_two_flat_halves():
+    h, w, S = 80, 120, 20
+    img = np.zeros((h, w, 4), np.uint8)
+    img[:, : w // 2] = (200, 50, 50, 0)
+    img[:, w // 2:] = (30, 180, 220, 0)
+    labels, lab, centers = ol.slic(img, S, 5, 5.0, 0, 0, want_centers=True)
+    mw, mh = w // S, h // S
+    assert labels.min() >= 0 and labels.max() < mw * mh
+    # no superpixel straddles the colour edge
+    left, right = set(np.unique(labels[:, : w // 2])), set(np.unique(labels[:, w // 2:]))
+    assert not (left & right)
+    # centres stay inside their half and their counts add up to the pixels their 3S x 48 windows can see
+    assert np.all(centers[:, 7] > 0)
+
+
+def test_ransac_recovers_a_plane_with_outliers():
+    rng = np.random.default_rng(3)
+    n_true = np.array([0.2, -0.3, -0.93])
+    n_true /= np.linalg.norm(n_true)
+    pts = rng.uniform(-1, 1, size=(4000, 3))
+    d_true = 5.0                                                               # n.X + d = 0
+    pts[:, 2] = -(d_true + n_true[0] * pts[:, 0] + n_true[1] * pts[:, 1]) / n_true[2]
+    pts[:, 2] += rng.normal(0, 2e-4, 4000) / abs(n_true[2])
+    pts[:600] += rng.uniform(-0.5, 0.5, size=(600, 3))                       # 15 % outliers
+    plane, best = ol.ransac_points(pts.astype(np.float32), region_size=20 * (0.004 / 0.0003) ** 2)
+    n = plane[:3] / np.linalg.norm(plane[:3])
+    assert abs(float(n @ n_true)) > 0.9995
+    assert abs(abs(plane[3]) - abs(d_true)) < 5e-3
+    assert best > 0.7 * 4000
+    # deterministic: same seed, same answer; different region id -> different draws
+    plane2, best2 = ol.ransac_points(pts.astype(np.float32), region_size=20 * (0.004 / 0.0003) ** 2)
+    assert np.array_equal(plane, plane2) and best == best2
+
+
+def test_wmf_keeps_a_consistent_plane_and_flags_an_outlier(small_scene):
+    sc = small_scene
+    h, w = sc.h, sc.w
+    o = _orc(sc)
+    n_world = np.ascontiguousarray((sc.gt_normal.numpy() @ sc.R[0]).astype(np.float32))
+    o.load_planes(sc.gt_depth.numpy(), n_world)          # ground-truth planes everywhere
+    o.getview()                                          # lines->depth = f*b/depth
+    o.scale[:] = 1.0
+    # corrupt one interior pixel on the back plane: its plane disagrees with every neighbour's
+    y, x = 8, 12
+    bad = o.norm4[y, x].copy()
+    bad[3] *= 1.6
+    o.norm4[y, x] = bad
+    for it in range(4):
+        o.wmf_detect(it)
+    assert o.scale[y, x] == 0.0
+    assert o.scale.mean() > 0.8
+    # the final pass refills it from its reliable neighbours
+    o.set_regions(np.zeros((h, w), np.int32), np.array([1.0], np.float32))
+    for it in range(3):
+        o.wmf_fill(it)
+    assert o.scale[y, x] == 1.0
+    d = o.compute_disp()[y, x, 3]
+    assert abs(d - sc.gt_depth.numpy()[y, x]) / sc.gt_depth.numpy()[y, x] < 0.02
