@@ -249,9 +249,9 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                     int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
-    if (ctx->window_sweep) {   // experimental LDS-window form (pm_sweep_win.hip), off by default: see DESIGN.md §4
+    if (ctx->lds_sweep) {   // opt-in LDS-patch form for 8-bit imagery, box 11, n_best <= 2, <= 10 views (pm_sweep_lds.hip)
         int launched = 0;
-        const int rc = launch_pm_sweep_win(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine, &launched);
+        const int rc = launch_pm_sweep_lds(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine, &launched);
         if (rc != TSAR_OK || launched) return rc;
     }
     const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;

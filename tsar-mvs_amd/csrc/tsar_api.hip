@@ -1,5 +1,6 @@
 // tsar_api.hip — the C ABI of include/tsar.h: context, device memory, camera algebra, call order.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -174,8 +175,10 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TSAR_ERR_HIP; }
     tsar_default_params(&ctx->params);
-    if (const char* e = getenv("TSAR_WINDOW_SWEEP")) ctx->window_sweep = e[0] == '1';
+    if (const char* e = getenv("TSAR_LDS_SWEEP")) ctx->lds_sweep = e[0] == '1';
     if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
+    if (const char* e = getenv("TSAR_DEBUG_COUNTERS"))
+        if (e[0] == '1' && hipMalloc((void**)&ctx->dbg, 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(ctx->dbg, 0, 8 * sizeof(unsigned long long));
     *out = ctx;
     return TSAR_OK;
 }
@@ -197,6 +200,12 @@ extern "C" int tsar_destroy(tsar_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
+    if (ctx->dbg) {
+        unsigned long long h[8] = {0};
+        hipMemcpy(h, ctx->dbg, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[tsar counters] lds-path wave evaluations %llu, gather-path %llu, vetoing lanes %llu\n", h[0], h[1], h[2]);
+        hipFree(ctx->dbg);
+    }
     free_views(ctx);
     free_planes(ctx);
     dev_free(ctx->dscene); dev_free(ctx->region_text); dev_free(ctx->region_size); dev_free(ctx->region_n4);

@@ -86,8 +86,9 @@ struct tsar_ctx {
     float4* region_n4 = nullptr;
     int sweeps_done = 0;         // RNG stream counter
     // timing
-    bool window_sweep = false;   // TSAR_WINDOW_SWEEP=1: LDS-window form of the sweep (pm_sweep_win.hip), experimental
+    bool lds_sweep = false;      // TSAR_LDS_SWEEP=1: LDS-patch form of the sweep (pm_sweep_lds.hip); bit-exact, not yet faster
     int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); 2 measured fastest
+    unsigned long long* dbg = nullptr;   // TSAR_DEBUG_COUNTERS=1: device counters printed by tsar_destroy
     bool timing = false;
     std::vector<KernelTimer> timers;
 };
@@ -115,7 +116,7 @@ int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, in
 int launch_pm_init(tsar_ctx* ctx);
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                     uint32_t stream_id, int do_prop, int do_refine);
-int launch_pm_sweep_win(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
+int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                         int do_prop, int do_refine, int* launched);
 int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio);
 int launch_get_disp(tsar_ctx* ctx, const float* depth_in, const float* normal_world);
