@@ -28,6 +28,7 @@
  *   sliccuda → gipuma_getview  (gipuma.cu:1188-1213)     tsar_getview
  *   gipuma_WMF / gipuma_WMF_Final (gipuma.cu:1294-1698)  tsar_wmf
  *   texture() output canny[]/text[] (main.cpp:559-593)   tsar_set_regions
+ *   texture() itself (main.cpp:365-596, CPU + OpenCV)     tsar_detect_weak_texture
  *   CPU RANSAC per region      (main.cpp:1520-1730)      tsar_ransac_regions
  *   fakecuda → gipuma_update_scale_2 (gipuma.cu:1261-92) tsar_fake_depth
  *   fillcuda → gipuma_update_scale + gipuma_compute_disp tsar_fill_textureless
@@ -184,6 +185,12 @@ int tsar_wmf(tsar_ctx* ctx, int iters, int final_pass);
  * regions (cannylines->text). */
 int tsar_set_regions(tsar_ctx* ctx, const int32_t* labels, int n_regions, const float* region_text,
                      const float* region_size, int mem);
+/* Weak-texture region detection of the reference view on the GPU (reference texture(), main.cpp:365-596):
+ * computes lines->canny / cannylines->text / size and installs them like tsar_set_regions.  labels_out
+ * [h][w] int32, text_out/size_out [cap] may be NULL.  The HoughLinesP boundary closing of the reference
+ * (OpenCV-internal) is not reproduced. */
+int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int mem, int* n_regions_out, float* text_out,
+                             float* size_out, int cap);
 /* GPU replacement of the per-region CPU RANSAC; region_planes_out [n_regions][4] may be NULL */
 int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, float* inlier_ratio_out);
 int tsar_set_region_planes(tsar_ctx* ctx, const float* region_planes);            /* host [n][4] */

@@ -328,3 +328,30 @@ def slic(bgra, spixel_size=20, iters=5, weight=5.0, connectivity=0, color_space=
     centers = np.empty((mw * mh, 8), np.float32)
     lib().orc_slic(_p(img), w, h, spixel_size, iters, C.c_float(weight), connectivity, color_space, _p(labels), _p(lab), _p(centers))
     return (labels, lab, centers) if want_centers else labels
+
+
+# ---- weak-texture detection (oracle/tsar_oracle_texture.c) ---------------------------------------------
+def weak_texture(gray_u8, connect="true"):
+    """CPU restatement of texture(): -> dict(labels4, labels, text, size, cenx, ceny, count, edge)"""
+    L = lib()
+    g = np.ascontiguousarray(gray_u8, np.uint8)
+    h, w = g.shape
+    w2, h2 = w // 2, h // 2
+    w4, h4 = w2 // 2, h2 // 2
+    d2 = np.empty((h2, w2), np.uint8)
+    d4 = np.empty((h4, w4), np.uint8)
+    L.orc_pyrdown(_p(g), w, h, _p(d2))
+    L.orc_pyrdown(_p(d2), w2, h2, _p(d4))
+    edge = np.empty((h4, w4), np.uint8)
+    L.orc_roberts_threshold(_p(d4), w4, h4, _p(edge))
+    L.orc_border_fix(_p(edge), w4, h4)
+    lab4 = np.empty((h4, w4), np.int32)
+    fn = L.orc_connect_true if connect == "true" else L.orc_connect_literal
+    fn.restype = C.c_int
+    n = fn(_p(edge), w4, h4, _p(lab4), None, 0)
+    text = np.empty(n, np.float32); size = np.empty(n, np.float32)
+    cenx = np.empty(n, np.int32); ceny = np.empty(n, np.int32); count = np.empty(n, np.int32)
+    L.orc_region_stats(_p(lab4), w4, h4, n, _p(text), _p(size), _p(cenx), _p(ceny), _p(count))
+    labels = np.empty((h, w), np.int32)
+    L.orc_upsample_labels(_p(lab4), w4, h4, w, h, _p(labels))
+    return dict(labels4=lab4, labels=labels, text=text, size=size, cenx=cenx, ceny=ceny, count=count, edge=edge, down4=d4)

@@ -371,3 +371,79 @@ def test_wmf_keeps_a_consistent_plane_and_flags_an_outlier(small_scene):
     assert o.scale[y, x] == 1.0
     d = o.compute_disp()[y, x, 3]
     assert abs(d - sc.gt_depth.numpy()[y, x]) / sc.gt_depth.numpy()[y, x] < 0.02
+
+
+# ---- row N2: weak-texture detection oracle ---------------------------------------------------------------
+def _ccl(img, kind):
+    import ctypes as C
+    L = ol.lib()
+    h, w = img.shape
+    lab = np.empty((h, w), np.int32)
+    fn = L.orc_connect_true if kind == "true" else L.orc_connect_literal
+    fn.restype = C.c_int
+    n = fn(img.ctypes.data_as(C.c_void_p), w, h, lab.ctypes.data_as(C.c_void_p), None, 0)
+    return lab, n
+
+
+def test_pyrdown_and_roberts_known_values():
+    import ctypes as C
+    L = ol.lib()
+    src = np.full((20, 24), 77, np.uint8)
+    dst = np.empty((10, 12), np.uint8)
+    L.orc_pyrdown(src.ctypes.data_as(C.c_void_p), 24, 20, dst.ctypes.data_as(C.c_void_p))
+    assert (dst == 77).all()                                   # the 5x5 kernel sums to 256
+    ramp = np.tile(np.arange(24, dtype=np.uint8) * 8, (20, 1))
+    L.orc_pyrdown(ramp.ctypes.data_as(C.c_void_p), 24, 20, dst.ctypes.data_as(C.c_void_p))
+    assert list(dst[5, 1:11]) == [16 * k for k in range(1, 11)]   # linear ramps survive away from the border
+    step = np.zeros((12, 12), np.uint8)
+    step[:, 6:] = 10
+    edge = np.empty_like(step)
+    L.orc_roberts_threshold(step.ctypes.data_as(C.c_void_p), 12, 12, edge.ctypes.data_as(C.c_void_p))
+    assert (edge[0] == 255).all() and (edge[:, 0] == 255).all()          # the 1-pixel frame is always "edge" (100*50 rule)
+    assert (edge[1:-1, 5] == 255).all() and (edge[1:-1, 2] == 0).all() and (edge[1:-1, 8] == 0).all()
+    big = np.zeros((4, 4), np.uint8)
+    big[1, 1] = 182; big[2, 2] = 0; big[2, 1] = 181; big[1, 2] = 0      # sqrt(182^2 + 181^2) = 256.7 -> (uchar) 0
+    L.orc_roberts_threshold(big.ctypes.data_as(C.c_void_p), 4, 4, edge[:4, :4].copy().ctypes.data_as(C.c_void_p))
+    out = np.empty((4, 4), np.uint8)
+    L.orc_roberts_threshold(big.ctypes.data_as(C.c_void_p), 4, 4, out.ctypes.data_as(C.c_void_p))
+    assert out[1, 1] == 0                                       # the reference's uchar wrap makes this strong edge "flat"
+
+
+def test_connected_components_numbering_and_the_reference_quirk():
+    Z, E = 0, 255
+    img = np.array([[Z, Z, E, Z, Z],
+                    [E, E, E, E, Z],
+                    [Z, Z, Z, E, Z],
+                    [Z, E, Z, Z, Z]], np.uint8)
+    lab, n = _ccl(img, "true")
+    assert n == 3                                               # label 0 (edges) + two components
+    assert lab[0, 0] == 1 and lab[0, 3] == 2 and lab[2, 0] == 2 and lab[0, 2] == 0
+    assert np.array_equal(_ccl(img, "literal")[0], lab)
+    # a shape where Connect()'s `connection[larger] = smaller` overwrites an earlier link (main.cpp:304-315):
+    # provisional label 3 is first merged into 1, then re-parented to 2, and the 1-3 link is lost
+    img = np.array([[Z, E, Z, E, Z, Z],
+                    [Z, E, Z, E, Z, E],
+                    [Z, E, Z, Z, Z, E],
+                    [Z, Z, Z, E, E, E]], np.uint8)
+    t, nt = _ccl(img, "true")
+    assert nt == 2                                              # everything is one component
+    l, nl = _ccl(img, "literal")
+    assert nl >= nt                                             # the reference may keep more labels than there are components
+
+
+def test_region_statistics_classification():
+    import ctypes as C
+    L = ol.lib()
+    w4, h4 = 200, 120
+    lab = np.zeros((h4, w4), np.int32)
+    lab[10:90, 10:90] = 1            # 6400 px, bbox 79x79 = 6241 < 2*6400 -> true weak
+    lab[100:110, 0:200] = 2          # 2000 px: below the 5000 px floor
+    lab[0:5, 100:110] = 3
+    n = 4
+    text = np.empty(n, np.float32); size = np.empty(n, np.float32); cx = np.empty(n, np.int32); cy = np.empty(n, np.int32); cnt = np.empty(n, np.int32)
+    L.orc_region_stats(lab.ctypes.data_as(C.c_void_p), w4, h4, n, *(a.ctypes.data_as(C.c_void_p) for a in (text, size, cx, cy, cnt)))
+    assert list(text) == [1, -1, 1, 1] and size[1] == 79 and cnt[1] == 6400
+    assert cx[1] == (sum(range(10, 90)) * 80 * 4) // 6400 and cy[2] == (sum(range(100, 110)) * 200 * 4) // 2000
+    out = np.empty((h4 * 4 + 3, w4 * 4 + 2), np.int32)
+    L.orc_upsample_labels(lab.ctypes.data_as(C.c_void_p), w4, h4, w4 * 4 + 2, h4 * 4 + 3, out.ctypes.data_as(C.c_void_p))
+    assert out[40, 40] == 1 and out[-1, -1] == lab[-1, -1] and out[400, 0] == 2

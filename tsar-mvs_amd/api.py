@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "tsar_default_params", "tsar_set_params", "tsar_set_views", "tsar_set_view_subset",
     "tsar_pm_init", "tsar_pm_iterate", "tsar_pm_sweep", "tsar_set_sweep_counter", "tsar_pm_cost_planes", "tsar_set_plane", "tsar_get_plane",
     "tsar_load_planes", "tsar_compute_disp", "tsar_compute_disp_final", "tsar_depth_to_plane", "tsar_get_result",
-    "tsar_set_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_ransac_regions",
+    "tsar_set_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic",
     "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
@@ -102,6 +102,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_getview.argtypes = [C.c_void_p]
     L.tsar_wmf.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.tsar_set_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_detect_weak_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int]
     L.tsar_ransac_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tsar_set_region_planes.argtypes = [C.c_void_p, C.c_void_p]
     L.tsar_fake_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -295,6 +296,17 @@ class Matcher:
         sz = np.ascontiguousarray(region_size, np.float32) if region_size is not None else None
         self._chk(self.L.tsar_set_regions(self._ctx, _ptr(lb)[0], len(tx), _ptr(tx)[0], _ptr(sz)[0], MEM_HOST))
         self.n_regions = len(tx)
+
+    def detect_weak_texture(self, cap: int = 1 << 16):
+        """-> (labels [h, w] int32, region_text [n], region_size [n]); also installs them as the regions"""
+        labels = np.empty((self.h, self.w), np.int32)
+        text = np.empty(cap, np.float32)
+        size = np.empty(cap, np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.tsar_detect_weak_texture(self._ctx, _ptr(labels)[0], MEM_HOST, C.byref(n), _ptr(text)[0], _ptr(size)[0], cap))
+        self.n_regions = n.value
+        k = min(n.value, cap)
+        return labels, text[:k].copy(), size[:k].copy()
 
     def ransac_regions(self):
         planes = np.empty((self.n_regions, 4), np.float32)

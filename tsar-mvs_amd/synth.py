@@ -91,7 +91,7 @@ class _Texture:
         return acc
 
 
-def _render(K, R, t, w, h, tex: _Texture, device, textureless: bool, want_gt: bool, tile_rows: int = 512):
+def _render(K, R, t, w, h, tex: _Texture, device, textureless: bool, want_gt: bool, tile_rows: int = 512, flat_cell: float = 0.9):
     """Ray-cast one view.  Returns (gray u8-valued float image, depth, normal_cam, prim, textured)."""
     Kinv = np.linalg.inv(K.astype(np.float64))
     Rt = R.astype(np.float64).T
@@ -146,7 +146,7 @@ def _render(K, R, t, w, h, tex: _Texture, device, textureless: bool, want_gt: bo
         tx = torch.ones_like(best_p, dtype=torch.bool)
         if textureless:
             # constant-albedo patches: squares of a coarse world-space checker on the planes
-            cell = (torch.floor(X[..., 0] / 0.9) + torch.floor(X[..., 1] / 0.9)).to(torch.int64)
+            cell = (torch.floor(X[..., 0] / flat_cell) + torch.floor(X[..., 1] / flat_cell)).to(torch.int64)
             tx = ~((cell % 3 == 0) & (best_p < 2))
             val = torch.where(tx, val, torch.full_like(val, 0.35) + 0.1 * best_p.to(val.dtype))
         g = torch.clamp(127.5 + 52.0 * val, 0, 255)
@@ -164,7 +164,7 @@ def _render(K, R, t, w, h, tex: _Texture, device, textureless: bool, want_gt: bo
 
 
 def make_scene(w: int, h: int, n_src: int, device="cpu", seed: int = 1234, cam_seed: int = 42,
-               textureless: bool = False, step: float = 0.03, tex_scale: float = 1.0) -> Scene:
+               textureless: bool = False, step: float = 0.03, tex_scale: float = 1.0, flat_cell: float = 0.9) -> Scene:
     """`n_src` source views + 1 reference view of the analytic scene at w x h.
     The texture's finest wavelength is ~4 pixels at every resolution (tex_scale rescales it)."""
     K, R, t = make_cameras(w, h, n_src, cam_seed, step)
@@ -175,7 +175,7 @@ def make_scene(w: int, h: int, n_src: int, device="cpu", seed: int = 1234, cam_s
     images = []
     gt = None
     for v in range(n_src + 1):
-        out = _render(K[v], R[v], t[v], w, h, tex, device, textureless, want_gt=(v == 0))
+        out = _render(K[v], R[v], t[v], w, h, tex, device, textureless, want_gt=(v == 0), flat_cell=flat_cell)
         images.append(out[0])
         if v == 0:
             gt = out[1:]
