@@ -38,6 +38,7 @@
  *   gipuma_dptow               (gipuma.cu:1140-1158)     tsar_depth_to_plane
  *   copy-out of norm4 (main.cpp:1785-1795)               tsar_get_result / tsar_get_plane
  *   gSLICr core_engine::Process_Frame + Get_Seg_Res      tsar_slic
+ *   Fusion.exe (binary only; flags x/1.sh:20-30)         tsar_fuse
  *
  * Conventions
  *   - every function returns an int status (TSAR_OK = 0, negative = error) and never exits the
@@ -203,6 +204,25 @@ void tsar_default_slic_settings(tsar_slic_settings* s);
  * labels_out [h][w] int32. */
 int tsar_slic(tsar_ctx* ctx, const uint8_t* bgra, int w, int h, const tsar_slic_settings* s,
               int32_t* labels_out, int mem);
+
+/* ---- depth-map fusion (row N3; the reference ships it only as Fusion.exe, flags x/1.sh:20-30) ----- */
+typedef struct tsar_fusion_params {
+    int32_t num_consistent;   /* --num_consistent=  (scripts: 1) */
+    float reproj_error;       /* --reproj_error=    (2 px) */
+    float depth_diff;         /* --depth_diff=      (0.01 relative) */
+    float angle_deg;          /* --angle=           (15 degrees between normals) */
+    int32_t used_list;        /* --used_list=       (1: pixels that contributed to a point are not fused again) */
+} tsar_fusion_params;
+void tsar_default_fusion_params(tsar_fusion_params* p);
+/* Fuses n_views depth/normal maps (what tsar_get_result exports: depth [h][w], world normals [h][w][3]) into
+ * one point cloud.  cams: K and world->camera R, t per view; gray: the views' images (point colour).  The
+ * source views of view v are src_idx[src_off[v] .. src_off[v+1]) (pair.txt as CSR).  points_out: up to `cap`
+ * records of 9 floats (x y z, nx ny nz, gray, number of agreeing views, reference view), in view order then
+ * raster order; *n_points_out is the number found (may exceed cap).  Context-free: runs on `device`. */
+int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth,
+              const float* const* normal_world, const float* const* gray, int mem, const int32_t* src_off,
+              const int32_t* src_idx, const tsar_fusion_params* params, float* points_out, int64_t cap,
+              int64_t* n_points_out);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream. */

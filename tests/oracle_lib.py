@@ -355,3 +355,33 @@ def weak_texture(gray_u8, connect="true"):
     labels = np.empty((h, w), np.int32)
     L.orc_upsample_labels(_p(lab4), w4, h4, w, h, _p(labels))
     return dict(labels4=lab4, labels=labels, text=text, size=size, cenx=cenx, ceny=ceny, count=count, edge=edge, down4=d4)
+
+
+# ---- fusion (oracle/tsar_oracle_fusion.c) ----------------------------------------------------------------
+class FusCam(C.Structure):
+    _fields_ = [("K", C.c_float * 9), ("R", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+def fuse(depths, normals, grays, K, R, t, pairs, num_consistent=1, reproj_error=2.0, depth_diff=0.01, angle_deg=15.0, used_list=1):
+    L = lib()
+    n = len(depths)
+    h, w = depths[0].shape
+    d = [np.ascontiguousarray(a, np.float32) for a in depths]
+    nr = [np.ascontiguousarray(a, np.float32) for a in normals]
+    g = [np.ascontiguousarray(a, np.float32) for a in grays]
+    mk = lambda seq: (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p) for a in seq])
+    cams = (FusCam * n)()
+    K = np.asarray(K, np.float32).reshape(n, 9); R = np.asarray(R, np.float32).reshape(n, 9); t = np.asarray(t, np.float32).reshape(n, 3)
+    for i in range(n):
+        cams[i].K[:] = K[i].tolist(); cams[i].R[:] = R[i].tolist(); cams[i].t[:] = t[i].tolist()
+    lists = [list(pairs[v]) for v in range(n)]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    idx = np.asarray([s for x in lists for s in x] or [0], np.int32)
+    cap = n * h * w
+    out = np.empty((cap, 9), np.float32)
+    cos_angle = np.float32(np.cos(np.float64(np.float32(angle_deg)) * 3.14159265358979323846 / 180.0))
+    L.orc_fuse.restype = C.c_int
+    cnt = L.orc_fuse(n, w, h, cams, mk(d), mk(nr), mk(g), _p(off), _p(idx), num_consistent, C.c_float(reproj_error), C.c_float(depth_diff),
+                     C.c_float(cos_angle), used_list, _p(out), cap)
+    return out[:cnt].copy()

@@ -406,3 +406,48 @@ def test_weak_texture_detection_matches_oracle():
     lit = ol.weak_texture(sc.images[0].numpy().astype(np.uint8), connect="literal")
     assert len(lit["text"]) >= len(ref["text"])
     m.close()
+
+
+# ---- row N3: fusion ----------------------------------------------------------------------------------------
+def test_fusion_bit_exact():
+    sc = synth.make_scene(160, 120, 4, seed=8, all_gt=True)
+    n = len(sc.images)
+    depths = [d.numpy() for d, _ in sc.meta["gt_all"]]
+    # perturb: a noisy band and some holes so that the consistency tests actually reject things
+    rng = np.random.default_rng(1)
+    for v in range(n):
+        depths[v] = depths[v] * (1 + rng.normal(0, 0.004, depths[v].shape).astype(np.float32))
+        depths[v][rng.uniform(size=depths[v].shape) < 0.05] = 0
+    normals = [np.ascontiguousarray((nc.numpy() @ sc.R[v]).astype(np.float32)) for v, (_, nc) in enumerate(sc.meta["gt_all"])]
+    grays = [im.numpy() for im in sc.images]
+    pairs = {v: [s for s in range(n) if s != v] for v in range(n)}
+    for num_consistent, used in ((1, 1), (2, 1), (2, 0)):
+        ref = ol.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, num_consistent=num_consistent, used_list=used)
+        prm = api.FusionParams(num_consistent, 2.0, 0.01, 15.0, used)
+        got = api.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, prm)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_end_to_end_match_then_fuse():
+    """PatchMatch every view on the GPU, fuse on the GPU, check the cloud against the analytic scene"""
+    sc = synth.make_scene(192, 128, 4, seed=8)
+    n = len(sc.images)
+    depths, normals = [], []
+    for ref in range(n):
+        order = [ref] + [v for v in range(n) if v != ref]
+        m = api.Matcher()
+        m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=3 + ref))
+        m.set_views([sc.images[v] for v in order], sc.K[order], sc.R[order], sc.t[order])
+        m.pm_init(); m.pm_iterate(4); m.compute_disp()
+        res = m.get_result(("depth", "normal"))
+        depths.append(res["depth"]); normals.append(res["normal"])
+        m.close()
+    pairs = {v: [s for s in range(n) if s != v] for v in range(n)}
+    pts = api.fuse(depths, normals, [im.numpy() for im in sc.images], sc.K, sc.R, sc.t, pairs, api.FusionParams(2, 2.0, 0.01, 15.0, 1))
+    assert len(pts) > 0.3 * sc.w * sc.h
+    X = pts[:, :3].astype(np.float64)
+    n0 = np.array([0.05, 0.02, -1.0]); n0 /= np.linalg.norm(n0)
+    n1 = np.array([0.55, 0.10, -1.0]); n1 /= np.linalg.norm(n1)
+    dist = np.minimum(np.minimum(np.abs(X @ n0 + 1.6), np.abs(X @ n1 - 0.15)), np.abs(np.linalg.norm(X - np.array([-0.9, 0.35, -0.2]), axis=1) - 0.75))
+    assert np.percentile(dist, 90) < 0.05

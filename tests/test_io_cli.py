@@ -93,3 +93,28 @@ def test_cli_matches_the_library(tmp_path):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert all(os.path.exists(root + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(4))
+
+
+FUSION = os.path.join(ROOT, "tsar-mvs_amd", "tsar_fusion")
+
+
+@pytest.mark.gpu
+def test_fusion_cli_reads_what_the_matcher_cli_writes(tmp_path):
+    """the reference's two-stage pipeline: per-view matcher runs, then `Fusion <dir> --num_consistent= 1 ...`
+    (x/1.sh:30, with its blank after '=') producing APD/APD_TSAR.ply"""
+    sc = synth.make_scene(160, 120, 3, seed=6)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    out = subprocess.run([CLI, "--all", "--gpus=1", "-mslp_folder", root, "-images_folder", root + "images/", "--iterations=3", "--blocksize=11", "--n_best=1"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    out = subprocess.run([FUSION, root, "--num_consistent=", "2", "--reproj_error=", "2", "--depth_diff=", "0.01", "--angle=", "15", "--used_list=", "1"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "num_consistent: 2" in out.stdout
+    raw = open(root + "APD/APD_TSAR.ply", "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    n = int([ln for ln in head.decode().splitlines() if ln.startswith("element vertex")][0].split()[-1])
+    assert n > 1000 and len(body) == n * 27
+    rec = np.frombuffer(body, dtype=np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3)]))
+    assert np.isfinite(rec["p"]).all() and np.allclose(np.linalg.norm(rec["n"], axis=1), 1, atol=1e-4)

@@ -447,3 +447,38 @@ def test_region_statistics_classification():
     out = np.empty((h4 * 4 + 3, w4 * 4 + 2), np.int32)
     L.orc_upsample_labels(lab.ctypes.data_as(C.c_void_p), w4, h4, w4 * 4 + 2, h4 * 4 + 3, out.ctypes.data_as(C.c_void_p))
     assert out[40, 40] == 1 and out[-1, -1] == lab[-1, -1] and out[400, 0] == 2
+
+
+# ---- row N3: fusion oracle -----------------------------------------------------------------------------
+def _fusion_inputs(w=96, h=64, n_src=3):
+    sc = synth.make_scene(w, h, n_src, seed=8, all_gt=True)
+    depths = [d.numpy() for d, _ in sc.meta["gt_all"]]
+    normals = [np.ascontiguousarray((n.numpy() @ sc.R[v]).astype(np.float32)) for v, (_, n) in enumerate(sc.meta["gt_all"])]   # world = R^T n_cam
+    grays = [im.numpy() for im in sc.images]
+    pairs = {v: [s for s in range(n_src + 1) if s != v] for v in range(n_src + 1)}
+    return sc, depths, normals, grays, pairs
+
+
+def test_fusion_of_ground_truth_maps_lands_on_the_surfaces():
+    sc, depths, normals, grays, pairs = _fusion_inputs()
+    pts = ol.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, num_consistent=2)
+    assert len(pts) > 0.5 * sc.w * sc.h
+    # every fused point is the mean of mutually consistent back-projections -> it lies on one of the analytic
+    # surfaces (back plane n.X = d, slanted plane, sphere), up to the fp32 depth/pixel rounding of the inputs
+    X = pts[:, :3].astype(np.float64)
+    n0 = np.array([0.05, 0.02, -1.0]); n0 /= np.linalg.norm(n0)
+    n1 = np.array([0.55, 0.10, -1.0]); n1 /= np.linalg.norm(n1)
+    d_plane0 = np.abs(X @ n0 - (-1.6)); d_plane1 = np.abs(X @ n1 - 0.15)
+    d_sph = np.abs(np.linalg.norm(X - np.array([-0.9, 0.35, -0.2]), axis=1) - 0.75)
+    dist = np.minimum(np.minimum(d_plane0, d_plane1), d_sph)
+    assert np.percentile(dist, 95) < 0.02
+    assert np.allclose(np.linalg.norm(pts[:, 3:6], axis=1), 1.0, atol=1e-5)
+    assert pts[:, 7].min() >= 2 and pts[:, 7].max() <= 3
+    # used_list: without marking, every view re-emits the surface it shares with the others
+    more = ol.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, num_consistent=2, used_list=0)
+    assert len(more) > 1.5 * len(pts)
+    # a stricter consistency count keeps fewer points; depth 0 pixels never fuse
+    assert len(ol.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, num_consistent=3)) < len(pts)
+    depths[0][:] = 0
+    z = ol.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, num_consistent=2)
+    assert not (z[:, 8] == 0).any()

@@ -45,6 +45,11 @@ class SlicSettings(C.Structure):
                 ("do_enforce_connectivity", C.c_int32), ("color_space", C.c_int32)]
 
 
+class FusionParams(C.Structure):
+    _fields_ = [("num_consistent", C.c_int32), ("reproj_error", C.c_float), ("depth_diff", C.c_float), ("angle_deg", C.c_float),
+                ("used_list", C.c_int32)]
+
+
 class KernelTiming(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
@@ -57,7 +62,7 @@ ABI_SYMBOLS = [
     "tsar_load_planes", "tsar_compute_disp", "tsar_compute_disp_final", "tsar_depth_to_plane", "tsar_get_result",
     "tsar_set_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
-    "tsar_default_slic_settings", "tsar_slic",
+    "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse",
     "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
 ]
 
@@ -108,6 +113,10 @@ def load_library(path: str = LIB_PATH):
     L.tsar_fake_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.tsar_fill_textureless.argtypes = [C.c_void_p]
     L.tsar_slic.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(SlicSettings), C.c_void_p, C.c_int]
+    L.tsar_default_fusion_params.restype = None
+    L.tsar_default_fusion_params.argtypes = [C.POINTER(FusionParams)]
+    L.tsar_fuse.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Camera), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
+                            C.c_void_p, C.c_void_p, C.POINTER(FusionParams), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.tsar_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.tsar_synchronize.argtypes = [C.c_void_p]
     L.tsar_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -368,3 +377,47 @@ def matcher_from_scene(scene, box=11, n_best=1, cost_comb=COMB_BEST_N, flags=0, 
     if subset is not None:
         m.set_view_subset(subset)
     return m
+
+
+def fuse(depths, normals, grays, K, R, t, pairs, params: FusionParams | None = None, cap: int | None = None, device: int = 0):
+    """Fuse per-view depth [h, w] / world-normal [h, w, 3] maps into a point cloud (tsar_fuse).
+    pairs: {view: [source views]} or list of lists.  Returns an [n, 9] float32 array:
+    x y z, nx ny nz, gray, number of agreeing views, reference view."""
+    L = load_library()
+    n = len(depths)
+    h, w = int(depths[0].shape[0]), int(depths[0].shape[1])
+    if params is None:
+        params = FusionParams()
+        L.tsar_default_fusion_params(C.byref(params))
+    keep, kinds = [], set()
+
+    def ptrs(seq, shape):
+        arr = (C.c_void_p * n)()
+        for i, a in enumerate(seq):
+            if not _is_torch(a):
+                a = np.ascontiguousarray(a, np.float32)
+                keep.append(a)
+            assert tuple(a.shape) == shape
+            p, kind = _ptr(a)
+            arr[i] = p
+            kinds.add(kind)
+        return arr
+    pd, pn, pg = ptrs(depths, (h, w)), ptrs(normals, (h, w, 3)), ptrs(grays, (h, w))
+    assert len(kinds) == 1
+    cams = (Camera * n)()
+    K = np.asarray(K, np.float32).reshape(n, 9); R = np.asarray(R, np.float32).reshape(n, 9); t = np.asarray(t, np.float32).reshape(n, 3)
+    for i in range(n):
+        cams[i].K[:] = K[i].tolist(); cams[i].R[:] = R[i].tolist(); cams[i].t[:] = t[i].tolist()
+    lists = [list(pairs[v]) for v in range(n)]
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(x) for x in lists])
+    idx = np.asarray([s for x in lists for s in x] or [0], np.int32)
+    if cap is None:
+        cap = n * h * w
+    out = np.empty((cap, 9), np.float32)
+    cnt = C.c_int64(0)
+    rc = L.tsar_fuse(device, n, w, h, cams, pd, pn, pg, kinds.pop(), off.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), C.byref(params),
+                     out.ctypes.data_as(C.c_void_p), cap, C.byref(cnt))
+    if rc != TSAR_OK:
+        raise TsarError(rc, "tsar_fuse failed")
+    return out[: min(cnt.value, cap)].copy()

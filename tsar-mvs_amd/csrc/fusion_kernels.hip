@@ -1,0 +1,186 @@
+// fusion_kernels.hip — geometric-consistency depth-map fusion on the GPU.
+// The reference ships the fuser only as a binary (Fusion.exe, driven by x/1.sh:20-30 with
+// --num_consistent= --reproj_error= --depth_diff= --angle= --used_list=); this is the published ACMH/ACMM
+// fusion that binary derives from, fed directly from device-resident depth / normal maps (e.g. the buffers
+// the RCCL gather of bench.py / driver.py delivers), so the pipeline closes on the GPU.
+//
+// One launch per reference view (views are processed in order because "used" marks made by one view gate
+// the next): each thread owns a pixel, back-projects it, visits its source views, and keeps the pixel when
+// enough sources agree.  Marks go to a second array that becomes visible when the next view starts, and the
+// accepted points are compacted in raster order (rocPRIM select), so the output is deterministic.
+#include <math.h>
+#include <rocprim/device/device_select.hpp>
+
+#include "tsar_dev.h"
+
+#define FU_BLOCK 256
+#define FU_MAX_SRC 64
+
+struct FuCam { float K[9], R[9], t[3]; };
+struct FuRec { float v[9]; };   // xyz, unit normal, gray, n_consistent, view
+
+__device__ __forceinline__ float fdot3(const float* a, const float* b) { return __builtin_fmaf(a[2], b[2], __builtin_fmaf(a[1], b[1], a[0] * b[0])); }
+__device__ __forceinline__ void unproject(const FuCam& c, float x, float y, float depth, float* X) {
+    const float pc[3] = {depth * (x - c.K[2]) / c.K[0], depth * (y - c.K[5]) / c.K[4], depth};
+    const float d[3] = {pc[0] - c.t[0], pc[1] - c.t[1], pc[2] - c.t[2]};
+    X[0] = __builtin_fmaf(c.R[6], d[2], __builtin_fmaf(c.R[3], d[1], c.R[0] * d[0]));
+    X[1] = __builtin_fmaf(c.R[7], d[2], __builtin_fmaf(c.R[4], d[1], c.R[1] * d[0]));
+    X[2] = __builtin_fmaf(c.R[8], d[2], __builtin_fmaf(c.R[5], d[1], c.R[2] * d[0]));
+}
+__device__ __forceinline__ void project(const FuCam& c, const float* X, float& px, float& py, float& depth) {
+    const float pc[3] = {fdot3(c.R, X) + c.t[0], fdot3(c.R + 3, X) + c.t[1], fdot3(c.R + 6, X) + c.t[2]};
+    depth = pc[2];
+    px = c.K[0] * pc[0] / pc[2] + c.K[2];
+    py = c.K[4] * pc[1] / pc[2] + c.K[5];
+}
+
+__global__ __launch_bounds__(FU_BLOCK) void fuse_view_kernel(int view, int w, int h, const FuCam* __restrict__ cams, const float* const* __restrict__ depth,
+                                                             const float* const* __restrict__ normal, const float* const* __restrict__ gray,
+                                                             const int32_t* __restrict__ src, int ns, const uint8_t* __restrict__ mask,
+                                                             uint8_t* __restrict__ pending, int num_consistent, float reproj_error, float depth_diff,
+                                                             float cos_angle, int use_marks, FuRec* __restrict__ rec, uint8_t* __restrict__ keep) {
+    const int p = blockIdx.x * FU_BLOCK + threadIdx.x;
+    const size_t np = (size_t)w * h;
+    if (p >= (int)np) return;
+    keep[p] = 0;
+    if (use_marks && mask[(size_t)view * np + p]) return;
+    const float ref_depth = depth[view][p];
+    if (!(ref_depth > 0.0f)) return;
+    const int r = p / w, c = p - r * w;
+    const FuCam ci = cams[view];
+    const float* rn = normal[view] + 3 * (size_t)p;
+    const float rnv[3] = {rn[0], rn[1], rn[2]};
+    float X[3];
+    unproject(ci, (float)c, (float)r, ref_depth, X);
+    float acc[3] = {X[0], X[1], X[2]}, nacc[3] = {rnv[0], rnv[1], rnv[2]}, gacc = gray[view][p];
+    int ncons = 0;
+    unsigned long long used_bits = 0ull;
+    int used_q[FU_MAX_SRC];
+    for (int k = 0; k < ns && k < FU_MAX_SRC; k++) {
+        const int j = src[k];
+        const FuCam cj = cams[j];
+        float sx, sy, sd;
+        project(cj, X, sx, sy, sd);
+        if (!(sd > 0.0f)) continue;
+        const int sr = (int)floorf(sy + 0.5f), scn = (int)floorf(sx + 0.5f);
+        if (sr < 0 || sr >= h || scn < 0 || scn >= w) continue;
+        const size_t q = (size_t)sr * w + scn;
+        if (use_marks && mask[(size_t)j * np + q]) continue;
+        const float src_depth = depth[j][q];
+        if (!(src_depth > 0.0f)) continue;
+        float Y[3], bx, by, bd;
+        unproject(cj, (float)scn, (float)sr, src_depth, Y);
+        project(ci, Y, bx, by, bd);
+        const float ex = (float)c - bx, ey = (float)r - by;
+        const float err = sqrtf(__builtin_fmaf(ex, ex, ey * ey));
+        const float rel = fabsf(bd - ref_depth) / ref_depth;
+        const float* sn = normal[j] + 3 * q;
+        const float snv[3] = {sn[0], sn[1], sn[2]};
+        const float cosang = fdot3(rnv, snv);
+        if (err < reproj_error && rel < depth_diff && cosang >= cos_angle) {
+            acc[0] += Y[0]; acc[1] += Y[1]; acc[2] += Y[2];
+            nacc[0] += snv[0]; nacc[1] += snv[1]; nacc[2] += snv[2];
+            gacc += gray[j][q];
+            used_bits |= 1ull << k;
+            used_q[k] = (int)q;
+            ncons++;
+        }
+    }
+    if (ncons < num_consistent) return;
+    const float inv = 1.0f / (float)(ncons + 1);
+    FuRec o;
+    o.v[0] = acc[0] * inv; o.v[1] = acc[1] * inv; o.v[2] = acc[2] * inv;
+    const float nn[3] = {nacc[0] * inv, nacc[1] * inv, nacc[2] * inv};
+    const float nl = 1.0f / sqrtf(fdot3(nn, nn));
+    o.v[3] = nn[0] * nl; o.v[4] = nn[1] * nl; o.v[5] = nn[2] * nl;
+    o.v[6] = gacc * inv; o.v[7] = (float)ncons; o.v[8] = (float)view;
+    rec[p] = o;
+    keep[p] = 1;
+    if (use_marks)
+        for (int k = 0; k < ns && k < FU_MAX_SRC; k++)
+            if (used_bits >> k & 1ull) pending[(size_t)src[k] * np + (size_t)used_q[k]] = 1;
+}
+
+extern "C" int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth, const float* const* normal_world,
+                         const float* const* gray, int mem, const int32_t* src_off, const int32_t* src_idx, const tsar_fusion_params* prm,
+                         float* points_out, int64_t cap, int64_t* n_points_out) {
+    if (n_views < 2 || w < 1 || h < 1 || !cams || !depth || !normal_world || !gray || !src_off || !src_idx || !prm || !n_points_out) return TSAR_ERR_INVALID;
+    if (mem != TSAR_MEM_DEVICE && mem != TSAR_MEM_HOST) return TSAR_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return TSAR_ERR_HIP;
+    const size_t np = (size_t)w * h;
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return TSAR_ERR_HIP;
+    std::vector<void*> to_free;
+    auto dmalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; to_free.push_back(p); return p; };
+    auto done = [&](int rc) { hipStreamSynchronize(st); for (void* p : to_free) hipFree(p); hipStreamDestroy(st); return rc; };
+    // inputs
+    std::vector<const float*> hd(n_views), hn(n_views), hg(n_views);
+    for (int v = 0; v < n_views; v++) {
+        if (!depth[v] || !normal_world[v] || !gray[v]) return done(TSAR_ERR_INVALID);
+        if (mem == TSAR_MEM_DEVICE) { hd[v] = depth[v]; hn[v] = normal_world[v]; hg[v] = gray[v]; }
+        else {
+            float *dd = (float*)dmalloc(np * 4), *dn = (float*)dmalloc(np * 12), *dg = (float*)dmalloc(np * 4);
+            if (!dd || !dn || !dg) return done(TSAR_ERR_NOMEM);
+            hipMemcpyAsync(dd, depth[v], np * 4, hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(dn, normal_world[v], np * 12, hipMemcpyHostToDevice, st);
+            hipMemcpyAsync(dg, gray[v], np * 4, hipMemcpyHostToDevice, st);
+            hd[v] = dd; hn[v] = dn; hg[v] = dg;
+        }
+    }
+    std::vector<FuCam> hc(n_views);
+    for (int v = 0; v < n_views; v++) { memcpy(hc[v].K, cams[v].K, 36); memcpy(hc[v].R, cams[v].R, 36); memcpy(hc[v].t, cams[v].t, 12); }
+    FuCam* d_cams = (FuCam*)dmalloc(sizeof(FuCam) * n_views);
+    const float **d_depth = (const float**)dmalloc(8 * n_views), **d_normal = (const float**)dmalloc(8 * n_views), **d_gray = (const float**)dmalloc(8 * n_views);
+    const int n_src_total = src_off[n_views];
+    int32_t* d_src = (int32_t*)dmalloc((size_t)(n_src_total > 0 ? n_src_total : 1) * 4);
+    uint8_t *mask = (uint8_t*)dmalloc((size_t)n_views * np), *pending = (uint8_t*)dmalloc((size_t)n_views * np), *keep = (uint8_t*)dmalloc(np);
+    FuRec *rec = (FuRec*)dmalloc(np * sizeof(FuRec)), *compact = (FuRec*)dmalloc(np * sizeof(FuRec));
+    unsigned int* d_count = (unsigned int*)dmalloc(4);
+    if (!d_cams || !d_depth || !d_normal || !d_gray || !d_src || !mask || !pending || !keep || !rec || !compact || !d_count) return done(TSAR_ERR_NOMEM);
+    hipMemcpyAsync(d_cams, hc.data(), sizeof(FuCam) * n_views, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync((void*)d_depth, hd.data(), 8 * n_views, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync((void*)d_normal, hn.data(), 8 * n_views, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync((void*)d_gray, hg.data(), 8 * n_views, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(d_src, src_idx, (size_t)n_src_total * 4, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(mask, 0, (size_t)n_views * np, st);
+    hipMemsetAsync(pending, 0, (size_t)n_views * np, st);
+    size_t tmp_bytes = 0;
+    if (rocprim::select(nullptr, tmp_bytes, rec, keep, compact, d_count, np, st) != hipSuccess) return done(TSAR_ERR_HIP);
+    void* tmp = dmalloc(tmp_bytes);
+    if (!tmp) return done(TSAR_ERR_NOMEM);
+    const float cos_angle = (float)cos((double)prm->angle_deg * 3.14159265358979323846 / 180.0);
+    int64_t n_out = 0;
+    for (int v = 0; v < n_views; v++) {
+        const int ns = src_off[v + 1] - src_off[v];
+        for (int k = 0; k < ns; k++)
+            if (src_idx[src_off[v] + k] < 0 || src_idx[src_off[v] + k] >= n_views) return done(TSAR_ERR_INVALID);
+        hipLaunchKernelGGL(fuse_view_kernel, dim3((unsigned)((np + FU_BLOCK - 1) / FU_BLOCK)), dim3(FU_BLOCK), 0, st, v, w, h, d_cams, d_depth, d_normal, d_gray,
+                           d_src + src_off[v], ns, mask, pending, prm->num_consistent, prm->reproj_error, prm->depth_diff, cos_angle, prm->used_list ? 1 : 0, rec, keep);
+        if (rocprim::select(tmp, tmp_bytes, rec, keep, compact, d_count, np, st) != hipSuccess) return done(TSAR_ERR_HIP);
+        unsigned int cnt = 0;
+        hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP);
+        if (points_out && n_out < cap) {
+            const int64_t take = (int64_t)cnt < cap - n_out ? (int64_t)cnt : cap - n_out;
+            hipMemcpyAsync(points_out + 9 * n_out, compact, (size_t)take * sizeof(FuRec), mem == TSAR_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
+        }
+        n_out += cnt;
+        if (prm->used_list) {   // marks of this view become visible to the next one; only its source views can have changed
+            for (int k = 0; k < ns; k++) {
+                const size_t o = (size_t)src_idx[src_off[v] + k] * np;
+                hipMemcpyAsync(mask + o, pending + o, np, hipMemcpyDeviceToDevice, st);
+            }
+        }
+    }
+    *n_points_out = n_out;
+    return done(hipStreamSynchronize(st) == hipSuccess ? TSAR_OK : TSAR_ERR_HIP);
+}
+
+extern "C" void tsar_default_fusion_params(tsar_fusion_params* p) {   // x/1.sh:20-25
+    if (!p) return;
+    p->num_consistent = 1;
+    p->reproj_error = 2.0f;
+    p->depth_diff = 0.01f;
+    p->angle_deg = 15.0f;
+    p->used_list = 1;
+}

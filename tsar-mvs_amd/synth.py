@@ -164,7 +164,7 @@ def _render(K, R, t, w, h, tex: _Texture, device, textureless: bool, want_gt: bo
 
 
 def make_scene(w: int, h: int, n_src: int, device="cpu", seed: int = 1234, cam_seed: int = 42,
-               textureless: bool = False, step: float = 0.03, tex_scale: float = 1.0, flat_cell: float = 0.9) -> Scene:
+               textureless: bool = False, step: float = 0.03, tex_scale: float = 1.0, flat_cell: float = 0.9, all_gt: bool = False) -> Scene:
     """`n_src` source views + 1 reference view of the analytic scene at w x h.
     The texture's finest wavelength is ~4 pixels at every resolution (tex_scale rescales it)."""
     K, R, t = make_cameras(w, h, n_src, cam_seed, step)
@@ -174,15 +174,18 @@ def make_scene(w: int, h: int, n_src: int, device="cpu", seed: int = 1234, cam_s
     tex = _Texture(seed, base)
     images = []
     gt = None
+    gt_all = []
     for v in range(n_src + 1):
-        out = _render(K[v], R[v], t[v], w, h, tex, device, textureless, want_gt=(v == 0), flat_cell=flat_cell)
+        out = _render(K[v], R[v], t[v], w, h, tex, device, textureless, want_gt=(v == 0 or all_gt), flat_cell=flat_cell)
         images.append(out[0])
         if v == 0:
             gt = out[1:]
+        if all_gt:
+            gt_all.append((out[1], out[2]))   # depth, camera-frame normal of every view (fusion tests)
     dmin = float(gt[0].min()) * 0.8
     dmax = float(gt[0].max()) * 1.25
     return Scene(w, h, images, K, R, t, dmin, dmax, gt[0], gt[1], gt[2], gt[3],
-                 meta={"seed": seed, "cam_seed": cam_seed, "step": step, "textureless": textureless})
+                 meta={"seed": seed, "cam_seed": cam_seed, "step": step, "textureless": textureless, "gt_all": gt_all})
 
 
 def gt_planes(scene: Scene) -> torch.Tensor:
