@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsar_hip.so")
+LIB_PATH = os.environ.get("TSAR_LIB") or os.path.join(_HERE, "libtsar_hip.so")     # TSAR_LIB: A/B builds only
 
 TSAR_OK = 0
 TSAR_ERR_INVALID, TSAR_ERR_HIP, TSAR_ERR_STATE, TSAR_ERR_NOMEM = -1, -2, -3, -4

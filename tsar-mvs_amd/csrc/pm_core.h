@@ -129,6 +129,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                       const PixelRef& pr, int x, int y, const float4& n4) {
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
+    const int qorg = (qp + 1) << 2;          // byte offset of quad entry (0 + 1, 0 + 1)
     float H[9];
     plane_homography(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
@@ -154,10 +155,21 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
                 v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
                 const float ax = __builtin_amdgcn_fractf(u), ay = __builtin_amdgcn_fractf(v);
-                const int iu = (int)floorf(u), iv = (int)floorf(v);
-                const uint32_t off = (uint32_t)(__mul24(iv + 1, qp) + iu + 1) * 4u;
+                int iu, iv;                                     // floor + convert in one instruction each
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
+                // byte offset of quad entry (iv + 1, iu + 1): one 24-bit multiply-add, one shift-add; the two +1 are
+                // folded into the uniform constant (qp + 1) * 4
+                int lin;
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
+                uint32_t off;
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
                 const uint32_t q = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
-                const float t00 = (float)(q & 0xffu), t10 = (float)((q >> 8) & 0xffu), t01 = (float)((q >> 16) & 0xffu), t11 = (float)(q >> 24);
+                float t00, t10, t01, t11;                       // the four texels: one convert each, no shifts/masks
+                asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q));
+                asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q));
+                asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q));
+                asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q));
                 const float top = fma_(ax, t10 - t00, t00);
                 const float bot = fma_(ax, t11 - t01, t01);
                 s = fma_(ay, bot - top, top);
