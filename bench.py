@@ -30,6 +30,18 @@ def alg_bytes_per_pixel_iteration(n_src: int) -> int:
     return 136 + 16 * (1 + n_src)
 
 
+def alg_flops_per_pixel_iteration(n_src: int, box: int, f: float, depth_min: float) -> float:
+    """FLOPs of one pixel-iteration as the reference writes it (no hoisting):
+    Hyp * N * (150 + 56 * S), Hyp = 8 propagation arms + R refinement steps, R = number of deltaZ values
+    max_disp/2, /10, ... >= 0.01 (gipuma.cu:1066-1090), S = taps of the dilated window."""
+    taps = len(range(-(box // 2), box // 2 + 1, 2)) ** 2
+    dz, r = f / depth_min / 2.0, 0
+    while dz >= 0.01:
+        r += 1
+        dz /= 10.0
+    return (8 + r) * n_src * (150.0 + 56.0 * taps)
+
+
 def traffic_from_profiles():
     """HBM bytes per pm_sweep launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
     --pmc WRITE_SIZE runs of this same command, profiles/r*/pmc_{fetch,write}_size_sweep.csv; bench.py cannot
@@ -81,8 +93,8 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=6048)
     ap.add_argument("--height", type=int, default=4032)
     ap.add_argument("--views", type=int, default=10, help="source views per reference view")
@@ -172,7 +184,10 @@ def main():
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic_from_profiles(),
                                 "kernel": "pm_sweep_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                                "note": "vector-L1 (TCP) access-rate bound, then FP32 VALU (SURVEY 8d: ~970 flop/B; profiles/r01/README.md); the HBM fraction is reported because the metric asks for it. traffic = committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, converged launches), null if absent"}
+                                "note": "the kernel is FP32-VALU bound (SURVEY 8d: ~970 flop/B; issue-slot accounting in profiles/r01/README.md), so the HBM fraction is small by construction and is reported because the metric asks for it; 'valu' prices the same launch against the 157.3 TFLOP/s FP32 vector peak with the reference's as-written flop count. traffic = committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, converged launches), null if absent"}
+            flops_per_launch = alg_flops_per_pixel_iteration(args.views, args.box, float(sc.K[0][0][0]), sc.depth_min) * (w * h / 2.0)
+            tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            line["roofline"]["valu"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flops_per_launch": flops_per_launch}
             line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

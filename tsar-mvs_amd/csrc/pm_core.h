@@ -131,7 +131,8 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
     const int qorg = (qp + 1) << 2;          // byte offset of quad entry (0 + 1, 0 + 1)
     float H[9];
-    plane_homography(sc->ref, vw, n4, H);
+    if (STRICT) plane_homography(sc->ref, vw, n4, H);
+    else plane_homography_fast(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     int tap = 0;
     auto column = [&](int i) {
@@ -164,7 +165,9 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
                 uint32_t off;
                 asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
-                const uint32_t q = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
+                uint32_t q;
+                if (V & 4) q = off * 2654435761u;             // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
+                else q = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
                 float t00, t10, t01, t11;                       // the four texels: one convert each, no shifts/masks
                 asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q));
                 asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q));
@@ -178,10 +181,11 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             }
             const float r = (float)tile[own + j * tw + i];
             const float wt = wts[tap * PM_BLOCK];
-            const float wr = wt * r, ws = wt * s;
+            const float ws = wt * s;
             sum_src += ws;
             sum_src_src = fma_(ws, s, sum_src_src);
-            sum_ref_src = fma_(wr, s, sum_ref_src);
+            if (STRICT) sum_ref_src = fma_(wt * r, s, sum_ref_src);      // (w r) s, the oracle's order
+            else sum_ref_src = fma_(ws, r, sum_ref_src);                 // (w s) r: one multiply fewer per tap
             ++tap;
         }
     };

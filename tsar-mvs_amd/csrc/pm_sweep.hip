@@ -14,28 +14,27 @@
 
 #define SWEEP_RH 16  // region 32 x 16 pixels = 256 pixels of the active colour
 
-struct Candidate {
-    int idx;    // pixel index of the neighbour whose plane is tried, -1 = arm skipped
-    int same;   // 1 if that neighbour has the active colour (read from same_in)
-};
+// A candidate is the pixel index of the neighbour whose plane is tried, with bit 30 set if that neighbour has the
+// active colour (its plane is read from same_in); -1 = arm skipped.
+#define CAND_SAME (1 << 30)
 
 // 8-arm adaptive candidate selection, gipuma.cu:874-1042.
 DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __restrict__ c_same, const float* __restrict__ c_other,
-                             int x, int y, Candidate cand[8]) {
+                             int x, int y, int cand[8]) {
     const int col = sc->w, row = sc->h;
     const int p = y * col + x;
     const bool fix_seed = sc->flags & TSAR_FLAG_FIX_DOWN_FAR_SEED, fix_cmp = sc->flags & TSAR_FLAG_FIX_RIGHT_FAR_CMP;
     float cmin;
     int cp, cs;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { cand[k].idx = -1; cand[k].same = 0; }
+    for (int k = 0; k < 8; k++) cand[k] = -1;
     // far arms: offsets 3, 5, ..., 23 along the axis -> always the other colour
     if (y > 2) {
         cp = p - 3 * col; cmin = c_other[cp];
 #pragma unroll
         for (int i = 1; i < 11; ++i)
             if (y > 2 + 2 * i) { const int q = p - (3 + 2 * i) * col; const float v = c_other[q]; if (v < cmin) { cmin = v; cp = q; } }
-        cand[0].idx = cp;
+        cand[0] = cp;
     }
     if (y < row - 3) {
         cp = p + 3 * col;
@@ -43,14 +42,14 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
 #pragma unroll
         for (int i = 1; i < 11; ++i)
             if (y < row - 3 - 2 * i) { const int q = p + (3 + 2 * i) * col; const float v = c_other[q]; if (v < cmin) { cmin = v; cp = q; } }
-        cand[1].idx = cp;
+        cand[1] = cp;
     }
     if (x > 2) {
         cp = p - 3; cmin = c_other[cp];
 #pragma unroll
         for (int i = 1; i < 11; ++i)
             if (x > 2 + 2 * i) { const int q = p - 3 - 2 * i; const float v = c_other[q]; if (v < cmin) { cmin = v; cp = q; } }
-        cand[2].idx = cp;
+        cand[2] = cp;
     }
     if (x < col - 3) {
         cp = p + 3; cmin = c_other[cp];
@@ -62,7 +61,7 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
                 const bool take = fix_cmp ? (v < cmin) : (cmin < v);             // gipuma.cu:943 is inverted
                 if (take) { cmin = v; cp = q; }
             }
-        cand[3].idx = cp;
+        cand[3] = cp;
     }
     // near arms: the 4-neighbour (other colour) and three V pairs (same colour)
     if (y > 0) {
@@ -72,7 +71,7 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
             if (y > 1 + i && x > i) { const int q = p - (2 + i) * col - i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
             if (y > 1 + i && x < col - 1 - i) { const int q = p - (2 + i) * col + i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
         }
-        cand[4].idx = cp; cand[4].same = cs;
+        cand[4] = cs ? (cp | CAND_SAME) : cp;
     }
     if (y < row - 1) {
         cp = p + col; cs = 0; cmin = c_other[cp];
@@ -81,7 +80,7 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
             if (y < row - 2 - i && x > i) { const int q = p + (2 + i) * col - i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
             if (y < row - 2 - i && x < col - 1 - i) { const int q = p + (2 + i) * col + i; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
         }
-        cand[5].idx = cp; cand[5].same = cs;
+        cand[5] = cs ? (cp | CAND_SAME) : cp;
     }
     if (x > 0) {
         cp = p - 1; cs = 0; cmin = c_other[cp];
@@ -90,7 +89,7 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
             if (x > 1 + i && y > i) { const int q = p - (2 + i) - i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
             if (x > 1 + i && y < row - 1 - i) { const int q = p - (2 + i) + i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
         }
-        cand[6].idx = cp; cand[6].same = cs;
+        cand[6] = cs ? (cp | CAND_SAME) : cp;
     }
     if (x < col - 1) {
         cp = p + 1; cs = 0; cmin = c_other[cp];
@@ -99,7 +98,7 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
             if (x < col - 2 - i && y > i) { const int q = p + (2 + i) - i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
             if (x < col - 2 - i && y < row - 1 - i) { const int q = p + (2 + i) + i * col; const float v = c_same[q]; if (v < cmin) { cmin = v; cp = q; cs = 1; } }
         }
-        cand[7].idx = cp; cand[7].same = cs;
+        cand[7] = cs ? (cp | CAND_SAME) : cp;
     }
 }
 
@@ -146,45 +145,47 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
         const DevRef& rf = sc->ref;
         float depth_now = plane_depth(rf, n_now, x, y);
         const float4 n_first = n_now;
-        if (do_prop) {
-            Candidate cand[8];
-            select_candidates(sc, c_same, c_other, x, y, cand);
+        // One rolled loop over the hypotheses of this pixel: h = 0..7 the propagation arms in the reference's
+        // order (gipuma.cu:874-1042), h = 8.. the refinement steps (:1066-1090).  The loop counter is wave-uniform,
+        // so the arm/step switch is a scalar branch and the multi-view cost (the whole tap loop) exists once in the
+        // binary instead of nine times: ~6 KB of hot code instead of ~45 KB, and fewer live registers.
+        int cand[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // neighbour pixel index | same-colour flag << 30, -1 = arm skipped
+        if (do_prop) select_candidates(sc, c_same, c_other, x, y, cand);
+        float vv[3];
+        view_vector(rf, x, y, vv);
+        float deltaN = 1.0f;
+        float deltaZ = sc->max_disp / 2.0f;
+        const float fb = rf.f * rf.baseline;
+        const int h_end = do_refine ? 8 + sc->refine_steps : 8;
+#pragma unroll 1
+        for (int h = do_prop ? 0 : 8; h < h_end; h++) {
+            float4 n_t;
+            float depth_t;
+            if (h < 8) {
+                int ci = cand[0];
 #pragma unroll
-            for (int a = 0; a < 8; a++) {
-                if (cand[a].idx < 0) continue;
-                const float4 nb = cand[a].same ? n_same[cand[a].idx] : n_other[cand[a].idx];
+                for (int a = 1; a < 8; a++) ci = (h == a) ? cand[a] : ci;
+                if (ci < 0) continue;
+                const int idx = ci & 0x3fffffff;
+                n_t = (ci >> 30) ? n_same[idx] : n_other[idx];
                 // A neighbour often carries the very plane this pixel already holds (or held when the launch
                 // started): planes spread by verbatim copies.  While c[p] is the score of norm4[p] (true for
                 // every state produced by init / sweeps) re-scoring it returns a cost that is not smaller
                 // than cost_now, so the reference's `cost_before < *cost_now` (gipuma.cu:555) rejects it.
-                if (cost_consistent && (same_bits(nb, n_now) || same_bits(nb, n_first))) continue;
-                const float depth_b = plane_depth(rf, nb, x, y);
+                if (cost_consistent && (same_bits(n_t, n_now) || same_bits(n_t, n_first))) continue;
+                depth_t = plane_depth(rf, n_t, x, y);
                 // spatialPropagation_cu gipuma.cu:524-566; the range test is done first: a
                 // hypothesis outside [depthMin, depthMax] is never accepted, so it is not scored.
-                if (!(depth_b >= rf.depthMin && depth_b <= rf.depthMax)) continue;
-                int bv; float rt;
-                const float cost_b = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, nb, bv, rt);
-                if (cost_b < cost_now) {
-                    cost_now = cost_b; n_now = nb; depth_now = depth_b;
-                    ratio_w = rt; beview_w = bv; wrote = true;
-                }
-            }
-        }
-        if (do_refine) {
-            // planeRefinement_cu gipuma.cu:621-676 + getRndDispAndUnitVector_cu :582-619
-            float vv[3];
-            view_vector(rf, x, y, vv);
-            float deltaN = 1.0f;
-            float deltaZ = sc->max_disp / 2.0f;
-            const float fb = rf.f * rf.baseline;
-            for (int step = 0; step < sc->refine_steps; step++) {
-                const Rand4 rn = philox_uniform4((uint32_t)p, stream_id, (uint32_t)step, sc->seed_lo, sc->seed_hi);
+                if (!(depth_t >= rf.depthMin && depth_t <= rf.depthMax)) continue;
+            } else {
+                // planeRefinement_cu gipuma.cu:621-676 + getRndDispAndUnitVector_cu :582-619
+                const Rand4 rn = philox_uniform4((uint32_t)p, stream_id, (uint32_t)(h - 8), sc->seed_lo, sc->seed_hi);
                 const float disp = fb / depth_now;
                 const float minDelta = -fminf(deltaZ, sc->min_disp + disp);   // "+" as written, gipuma.cu:601
                 const float maxDelta = fminf(deltaZ, sc->max_disp - disp);
                 const float dz = between(rn.u[0], minDelta, maxDelta);
                 const float dispOut = fminf(fmaxf(disp + dz, sc->min_disp), sc->max_disp);
-                const float depthOut = fb / dispOut;
+                depth_t = fb / dispOut;
                 float nt[3];
                 nt[0] = n_now.x + between(rn.u[1], -deltaN, deltaN);
                 nt[1] = n_now.y + between(rn.u[2], -deltaN, deltaN);
@@ -192,17 +193,16 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
                 const float inv = 1.0f / sqrtf(dot3(nt, nt));
                 nt[0] *= inv; nt[1] *= inv; nt[2] *= inv;
                 if (dot3(nt, vv) > 0.0f) { nt[0] = -nt[0]; nt[1] = -nt[1]; nt[2] = -nt[2]; }
-                float4 n_t;
                 n_t.x = nt[0]; n_t.y = nt[1]; n_t.z = nt[2];
-                n_t.w = plane_offset(rf, nt, x, y, depthOut);
-                int bv; float rt;
-                const float cost_t = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
-                if (cost_t < cost_now) {
-                    cost_now = cost_t; n_now = n_t; depth_now = depthOut;
-                    ratio_w = rt; beview_w = bv; wrote = true;
-                }
+                n_t.w = plane_offset(rf, nt, x, y, depth_t);
                 deltaN = deltaN / 4.0f;
                 deltaZ = deltaZ / 10.0f;
+            }
+            int bv; float rt;
+            const float cost_t = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
+            if (cost_t < cost_now) {
+                cost_now = cost_t; n_now = n_t; depth_now = depth_t;
+                ratio_w = rt; beview_w = bv; wrote = true;
             }
         }
     }
@@ -240,6 +240,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             case 1: return launch_sweep_t<2, 5, false, true, 1>(ctx, colour, a, b, c, sid, dp, dr);
             case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
             case 3: return launch_sweep_t<2, 5, false, true, 3>(ctx, colour, a, b, c, sid, dp, dr);
+            case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
             default: break;
         }
     }

@@ -109,7 +109,15 @@ static void derive_cameras(tsar_ctx* ctx, const tsar_camera* cams) {
         DevView& dv = sc.view[v];
         for (int i = 0; i < 9; i++) { dv.K[i] = (float)Kv[i]; dv.R[i] = (float)Rrel[i]; }
         for (int r = 0; r < 3; r++) dv.t[r] = (float)trel[r];
-        dv.pad_ = 0.f;
+        dv.pad_ = dv.pad2_ = 0.f;
+        {                                                        // fast-mode split of the plane homography: A = K R K0^-1, b = K t
+            double K0inv[9], KR[9], A[9];
+            inv3(K0, K0inv);
+            mul3(Kv, Rrel, KR);
+            mul3(KR, K0inv, A);
+            for (int i = 0; i < 9; i++) dv.A[i] = (float)A[i];
+            for (int r = 0; r < 3; r++) dv.b[r] = (float)(Kv[3 * r] * trel[0] + Kv[3 * r + 1] * trel[1] + Kv[3 * r + 2] * trel[2]);
+        }
         if (v == 0) {
             DevRef& rf = sc.ref;
             double Kinv[9], M[9], Minv[9];

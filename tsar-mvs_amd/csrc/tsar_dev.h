@@ -16,6 +16,9 @@ struct DevView {
     float R[9];
     float t[3];
     float pad_;
+    float A[9];              // K R K_ref^-1  (fast-mode homography H = A - b m^T, m = K_ref^-T n / d)
+    float b[3];              // K t
+    float pad2_;
     const float* img;        // [h][w] float gray
     const uint32_t* quad;    // [(h+2)][(w+2)] packed 2x2 texel quads (8-bit images only), see tex_kernels.hip
 };

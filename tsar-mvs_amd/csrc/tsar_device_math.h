@@ -111,3 +111,17 @@ DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n
     mat3mul(M, rf.Kinv, T);
     mat3mul(vw.K, T, H);
 }
+
+// Fast mode: the same homography as A - b m^T with A = K R K_ref^-1 and b = K t folded per view on the host
+// (tsar_api.hip derive_cameras) and m = K_ref^-T n / d, which depends on the plane only, so the compiler hoists it
+// out of the view loop: 9 FMAs per view instead of two 3x3 products.  Rounding differs from plane_homography.
+DEVFN void plane_homography_fast(const DevRef& rf, const DevView& vw, const float4& n4, float* H) {
+    const float inv_d = __builtin_amdgcn_rcpf(n4.w);
+    float m[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) m[c] = fma_(n4.z, rf.Kinv[6 + c], fma_(n4.y, rf.Kinv[3 + c], n4.x * rf.Kinv[c])) * inv_d;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) H[r * 3 + c] = fma_(-vw.b[r], m[c], vw.A[r * 3 + c]);
+}
