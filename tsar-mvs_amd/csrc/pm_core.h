@@ -64,10 +64,18 @@ struct PixelRef {
 };
 
 // Stage the reference window of this workgroup's region in LDS.  tile is (RW + 2hr) x (RH + 2vr).
-// Reference-window texel type: 8-bit imagery (QUAD path) keeps the window as bytes, which is what lets
-// four 256-thread workgroups (weights 36 KiB + window 1 KiB each) share one CU's 160 KiB of LDS.
+// Reference-window texel type: 8-bit imagery (QUAD path) keeps the window as 16-bit entries holding the upper half
+// of each texel's fp32 pattern (bf16; exact for the integers 0..255), which is what lets four 256-thread workgroups
+// (weights 36 KiB + window 2.1 KiB each) share one CU's 160 KiB of LDS, and lets the fast tap loop load a texel
+// straight into the upper half of a register (ds_read_u16_d16_hi) with no convert instruction.
 template <bool QUAD> struct TileOf { typedef float type; };
-template <> struct TileOf<true> { typedef unsigned char type; };
+template <> struct TileOf<true> { typedef unsigned short type; };     // upper half of the fp32 pattern: exact for 0..255
+DEVFN float tile_value(float t) { return t; }
+DEVFN float tile_value(unsigned short t) { return __uint_as_float((uint32_t)t << 16); }
+DEVFN float tile_value(unsigned char t) { return (float)t; }               // pm_sweep_lds.hip keeps a byte window
+DEVFN void tile_store(unsigned char* t, float v) { *t = (unsigned char)v; }
+DEVFN void tile_store(float* t, float v) { *t = v; }
+DEVFN void tile_store(unsigned short* t, float v) { *t = (unsigned short)(__float_as_uint(v) >> 16); }
 template <bool QUAD>
 __host__ __device__ constexpr size_t tile_bytes(int tw, int th) {
     return ((size_t)tw * th * sizeof(typename TileOf<QUAD>::type) + 15) & ~(size_t)15;
@@ -81,7 +89,7 @@ DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, TileT* tile, int x0, 
     for (int k = threadIdx.x; k < tw * th; k += PM_BLOCK) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = min(max(x0 + tx - hr, 0), w - 1), gy = min(max(y0 + ty - vr, 0), h - 1);
-        tile[k] = (TileT)img[(size_t)gy * w + gx];
+        tile_store(&tile[k], img[(size_t)gy * w + gx]);
     }
 }
 
@@ -90,14 +98,14 @@ DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, TileT* tile, int x0, 
 template <int HR, typename TileT>
 DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, int hr_rt, int vr_rt) {
     const int hr = HR > 0 ? HR : hr_rt, vr = HR > 0 ? HR : vr_rt;
-    const float cen = (float)tile[own];
+    const float cen = tile_value(tile[own]);
     float sum_ref = 0.f, sum_ref_ref = 0.f, wsum = 0.f;
     int tap = 0;
 #pragma unroll
     for (int i = -hr; i <= hr; i += 2) {
 #pragma unroll
         for (int j = -vr; j <= vr; j += 2) {
-            const float r = (float)tile[own + j * tw + i];
+            const float r = tile_value(tile[own + j * tw + i]);
             const float sd = sqrtf((float)(i * i + j * j));
             const float cd = fabsf(r - cen);
             const float wt = tsar_expf(-sd / 50.0f - cd / 18.0f);   // sigma_spatial 5, sigma_color 3 (gipuma.cu:248-249,268)
@@ -124,6 +132,8 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //   bit 0: two tap columns per trip (12 gathers in flight per wave instead of 6)
 //   bit 1: fast mode only — clamp with v_med3_f32 and take the fraction with v_fract_f32
 //          (differs from floor/subtract only for u in (-2^-24, 0), where fract saturates below 1)
+//   bit 2: experiment — no gather (texel bits synthesised from the address): the VALU floor of the kernel
+//   bit 3: fast mode, radius 5 — reference-window texels loaded with ds_read_u16_d16_hi (no convert instruction)
 template <int HR, bool STRICT, bool QUAD, int V = 0>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
                       const PixelRef& pr, int x, int y, const float4& n4) {
@@ -138,6 +148,20 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     auto column = [&](int i) {
         const float xi = (float)(x + i);
         const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
+        float rcol[6];
+        if (QUAD && !STRICT && (V & 8) && HR == 5) {
+            // the column's six reference texels, each loaded into bits 31:16 of a register = its fp32 value.  gfx950 runs
+            // with SRAM ECC, where a D16 load writes the whole register (zeros in the other half); tsar_create probes
+            // this once and falls back to the variant without bit 3 if it does not hold.  The loads are invisible to the
+            // compiler's waitcnt bookkeeping, which stays correct (LDS returns in order, its own waits only get more
+            // conservative); the wait for these six is the asm before their first use below.  Neither asm is volatile
+            // (a volatile one fences the gathers and serialises the taps); the unused bz operand keeps the loads inside
+            // the column loop instead of being hoisted out of the view and hypothesis loops into 36 live registers.
+            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(tile + own + i - 5 * tw);
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++)
+                asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"(jj * 2 * (PM_RW + 10) * 2), "v"(bz));
+        }
 #pragma unroll
         for (int j = -vr; j <= vr; j += 2) {
             const float yj = (float)(y + j);
@@ -179,7 +203,15 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             } else {
                 s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
             }
-            const float r = (float)tile[own + j * tw + i];
+            float r;
+            if (QUAD && !STRICT && (V & 8) && HR == 5) {
+                // tied to s so that the wait cannot be scheduled ahead of the gather's return, by which time the LDS
+                // loads issued at the top of the column have long completed
+                asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[(j + 5) >> 1]), "+v"(s));
+                r = rcol[(j + 5) >> 1];
+            } else {
+                r = tile_value(tile[own + j * tw + i]);
+            }
             const float wt = wts[tap * PM_BLOCK];
             const float ws = wt * s;
             sum_src += ws;

@@ -102,6 +102,28 @@ DEVFN void select_candidates(const DevScene* __restrict__ sc, const float* __res
     }
 }
 
+// Variant bit 3 of the fast tap loop relies on D16 LDS loads writing the whole destination register (zeros in the
+// half that is not loaded), which is how gfx950 behaves with SRAM ECC enabled.  Checked once per context.
+__global__ void d16_probe_kernel(uint32_t* out) {
+    __shared__ unsigned short t[64];
+    t[threadIdx.x] = (unsigned short)(0x4300u + threadIdx.x);
+    __syncthreads();
+    uint32_t r = 0xffffffffu;
+    const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(t + threadIdx.x);
+    asm volatile("ds_read_u16_d16_hi %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(addr));
+    out[threadIdx.x] = r;
+}
+bool probe_d16_hi_zeroes(tsar_ctx* ctx) {
+    uint32_t* d = nullptr;
+    uint32_t h[64];
+    if (hipMalloc((void**)&d, sizeof h) != hipSuccess) return false;
+    hipLaunchKernelGGL(d16_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+    bool ok = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    hipFree(d);
+    for (int i = 0; ok && i < 64; i++) ok = h[i] == ((0x4300u + i) << 16);
+    return ok;
+}
+
 DEVFN bool same_bits(const float4& a, const float4& b) {
     return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
            __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
@@ -241,6 +263,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
             case 3: return launch_sweep_t<2, 5, false, true, 3>(ctx, colour, a, b, c, sid, dp, dr);
             case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
+            case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
             default: break;
         }
     }

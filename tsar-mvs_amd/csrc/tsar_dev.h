@@ -90,7 +90,7 @@ struct tsar_ctx {
     int sweeps_done = 0;         // RNG stream counter
     // timing
     bool lds_sweep = false;      // TSAR_LDS_SWEEP=1: LDS-patch form of the sweep (pm_sweep_lds.hip); bit-exact, not yet faster
-    int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); 2 measured fastest
+    int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); tsar_create picks 10 (med3/fract + D16 window loads) when the D16 probe passes, else 2
     unsigned long long* dbg = nullptr;   // TSAR_DEBUG_COUNTERS=1: device counters printed by tsar_destroy
     bool timing = false;
     std::vector<KernelTimer> timers;
@@ -117,6 +117,7 @@ struct ScopedKernelTimer {
 // ---- launchers implemented in the .hip files -----------------------------------------------------
 int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, int h, int* nonintegral_flag);
 int launch_pm_init(tsar_ctx* ctx);
+bool probe_d16_hi_zeroes(tsar_ctx* ctx);   // pm_sweep.hip
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                     uint32_t stream_id, int do_prop, int do_refine);
 int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
