@@ -281,6 +281,19 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
 // XCD-aware tile order (guide §5.5 T1): workgroups are dealt round-robin to the 8 XCDs, so remap the
 // linear id such that each XCD walks one contiguous band of tiles and neighbouring tiles (which share
 // reference halo and source footprints) hit the same 4 MiB L2.  Bijective for any n.
+// Tile order inside that walk: strips of `sw` tiles across, row-major inside a strip, so that the ~128 workgroups
+// an XCD has in flight cover a compact 2-D patch (sw x 8 tiles) of the reference image: their source footprints then
+// overlap in both directions and fit the XCD's 4 MiB L2, instead of one 1-tile-high band as wide as the image.
+// sw <= 0: plain row-major.
+DEVFN void strip_tile(int t, int tiles_x, int tiles_y, int sw, int& tx, int& ty) {
+    if (sw <= 0) { ty = t / tiles_x; tx = t - ty * tiles_x; return; }
+    const int per_strip = sw * tiles_y;
+    const int strip = t / per_strip, within = t - strip * per_strip;
+    const int width = min(sw, tiles_x - strip * sw);      // the last strip may be narrower
+    ty = within / width;
+    tx = strip * sw + within - ty * width;
+}
+
 DEVFN int xcd_tile(int bid, int n) {
     const int chunk = n >> 3, rem = n & 7;
     const int xcd = bid & 7, slot = bid >> 3;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
                                                             int32_t* __restrict__ beview_out, uint32_t stream_id, int do_prop,
-                                                            int do_refine, int tiles_x, int n_tiles, int cost_consistent) {
+                                                            int do_refine, int tiles_x, int n_tiles, int cost_consistent, int strip_w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename TileOf<QUAD>::type TileT;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
@@ -144,7 +144,9 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
     float* wts = (float*)(lds_raw + tile_bytes<QUAD>(tw, th)) + threadIdx.x;
 
     const int t = xcd_tile(blockIdx.x, n_tiles);
-    const int ty0 = (t / tiles_x) * SWEEP_RH, tx0 = (t % tiles_x) * PM_RW;
+    int tix, tiy;
+    strip_tile(t, tiles_x, n_tiles / tiles_x, strip_w, tix, tiy);
+    const int ty0 = tiy * SWEEP_RH, tx0 = tix * PM_RW;
     stage_ref_tile<SWEEP_RH, TileT>(sc, tile, tx0, ty0, hr, vr);
     __syncthreads();
 
@@ -247,7 +249,7 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
         ScopedKernelTimer tm(ctx, "pm_sweep");
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
                            other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles,
-                           ctx->cost_consistent ? 1 : 0);
+                           ctx->cost_consistent ? 1 : 0, ctx->strip_w);
     }
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;
