@@ -115,15 +115,23 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     dist = None
+    # TSAR_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, results are staged through host memory for the gather); never used for a reported number.
+    backend = os.environ.get("TSAR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     from tsar_mvs_amd import api, synth
-    from tsar_mvs_amd.driver import gather_results
+    from tsar_mvs_amd.driver import alloc_gather_buffers, gather_results
 
     # each rank owns one reference view of the scene (its own camera arc position), SURVEY §8(e)
     sc = synth.make_scene(args.width, args.height, args.views, device=dev, seed=1234, cam_seed=42 + rank, step=args.cam_step)
@@ -133,13 +141,20 @@ def main():
     out_normal = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
     out_cost = torch.empty((h, w), dtype=torch.float32, device=dev)
 
+    results = [out_depth, out_normal, out_cost]
+    staged = [t.cpu() for t in results] if (dist is not None and backend != "nccl") else None
+    gathered = alloc_gather_buffers(dist, staged if staged is not None else results, dst=0) if dist is not None else None
+
     def step():
         m.pm_init()
         m.pm_iterate(args.iters)
         m.compute_disp()
         m.get_result_device(depth=out_depth, normal=out_normal, cost=out_cost)
         if dist is not None:
-            gather_results(dist, [out_depth, out_normal, out_cost], dst=0)
+            if staged is not None:
+                for s_, t in zip(staged, results):
+                    s_.copy_(t)
+            gather_results(dist, staged if staged is not None else results, dst=0, out=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -157,7 +172,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -170,7 +185,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * w * h * args.steps / dt / 1e6
         line = {
-            "metric": "depthmap Mpixels/sec (ETH3D full-res, 8 iters)", "value": value, "unit": "Mpix/s", "n_gpus": world,
+            "metric": "depthmap Mpixels/sec (ETH3D full-res, 8 iters)", "value": value, "unit": "Mpix/s", "n_gpus": world if backend == "nccl" else min(world, torch.cuda.device_count()),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ETH3D-size view {w}x{h}, 1 ref + {args.views} src views, {args.iters} PatchMatch iters, box {args.box}, n_best {args.n_best}; one ref view per GPU",

@@ -18,18 +18,27 @@ def owner_of_view(view: int, world: int) -> int:
     return view % world
 
 
-def gather_results(dist, tensors: Sequence, dst: int = 0):
+def alloc_gather_buffers(dist, tensors: Sequence, dst: int = 0):
+    """Receive buffers for gather_results on `dst` (None elsewhere), so that a loop gathers into the same memory."""
+    import torch
+    if dist.get_rank() != dst:
+        return None
+    return [[torch.empty_like(t) for _ in range(dist.get_world_size())] for t in tensors]
+
+
+def gather_results(dist, tensors: Sequence, dst: int = 0, out=None):
     """Gather each rank's result tensors to `dst` (RCCL on GPUs, gloo in the CPU tests).
-    Returns on dst a list (per tensor) of lists (per rank); elsewhere None."""
+    Returns on dst a list (per tensor) of lists (per rank) — `out` if given (alloc_gather_buffers) —
+    elsewhere None."""
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
-    out = []
-    for t in tensors:
+    res = []
+    for k, t in enumerate(tensors):
         if rank == dst:
-            bucket = [torch.empty_like(t) for _ in range(world)]
+            bucket = out[k] if out is not None else [torch.empty_like(t) for _ in range(world)]
             dist.gather(t, bucket, dst=dst)
-            out.append(bucket)
+            res.append(bucket)
         else:
             dist.gather(t, None, dst=dst)
-    return out if rank == dst else None
+    return res if rank == dst else None
