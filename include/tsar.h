@@ -78,6 +78,8 @@ extern "C" {
 /* cost combination, reference algorithmparameters.h:17 */
 #define TSAR_COMB_ALL 0
 #define TSAR_COMB_BEST_N 1
+#define TSAR_COMB_ANGLE 2   /* accepted like the reference: only BEST_N is distinguished on the GPU path (gipuma.cu:496-499), */
+#define TSAR_COMB_GOOD 3    /* so ANGLE and GOOD average all valid views exactly as ALL does */
 
 /* behaviour flags (tsar_params.flags).  Default 0 = the reference's behaviour wherever it is
  * well defined. */

@@ -43,7 +43,7 @@ def _random_planes(scene, orc, seed):
     return planes
 
 
-@pytest.mark.parametrize("box,n_best,comb", [(11, 1, 1), (11, 2, 1), (7, 3, 1), (11, 1, 0), (19, 2, 1)])
+@pytest.mark.parametrize("box,n_best,comb", [(11, 1, 1), (11, 2, 1), (7, 3, 1), (11, 1, 0), (19, 2, 1), (11, 1, 2), (11, 1, 3)])
 def test_cost_planes_strict_bit_exact(small_scene, box, n_best, comb):
     sc = small_scene
     orc = _oracle(sc, box=box, n_best=n_best, cost_comb=comb)

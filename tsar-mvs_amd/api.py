@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("TSAR_LIB") or os.path.join(_HERE, "libtsar_hip.so")  
 TSAR_OK = 0
 TSAR_ERR_INVALID, TSAR_ERR_HIP, TSAR_ERR_STATE, TSAR_ERR_NOMEM = -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
-COMB_ALL, COMB_BEST_N = 0, 1
+COMB_ALL, COMB_BEST_N, COMB_ANGLE, COMB_GOOD = 0, 1, 2, 3
 FLAG_FIX_DOWN_FAR_SEED, FLAG_FIX_RIGHT_FAR_CMP, FLAG_STRICT_DIV = 1, 2, 4
 MAXCOST = 2.0
 MAX_VIEWS = 64

@@ -255,7 +255,7 @@ extern "C" int tsar_set_params(tsar_ctx* ctx, const tsar_params* p) {
     if (!p) return fail(ctx, TSAR_ERR_INVALID, "params is NULL");
     if (p->box_hsize < 1 || p->box_vsize < 1 || p->box_hsize > 63 || p->box_vsize > 63) return fail(ctx, TSAR_ERR_INVALID, "box size must be in 1..63");
     if (p->n_best < 1) return fail(ctx, TSAR_ERR_INVALID, "n_best must be >= 1");
-    if (p->cost_comb != TSAR_COMB_ALL && p->cost_comb != TSAR_COMB_BEST_N) return fail(ctx, TSAR_ERR_INVALID, "cost_comb must be TSAR_COMB_ALL or TSAR_COMB_BEST_N");
+    if (p->cost_comb < TSAR_COMB_ALL || p->cost_comb > TSAR_COMB_GOOD) return fail(ctx, TSAR_ERR_INVALID, "cost_comb must be one of TSAR_COMB_ALL / BEST_N / ANGLE / GOOD");
     if (!(p->depth_min > 0.f) || !(p->depth_max > p->depth_min)) return fail(ctx, TSAR_ERR_INVALID, "need 0 < depth_min < depth_max");
     if (!(p->cam_scale > 0.f)) return fail(ctx, TSAR_ERR_INVALID, "cam_scale must be > 0");
     ctx->params = *p;

@@ -60,7 +60,7 @@ static void mkdirs(const std::string& path) {
 
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
-           "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n] [--n_best=N] [--cam_scale=S]\n"
+           "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
            "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load] [--seed=S] [--strict] [--fix-quirks]\n"
            "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
@@ -80,7 +80,9 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
             const char* v = a + 12;
             if (!strcmp(v, "all")) o.cost_comb = TSAR_COMB_ALL;
             else if (!strcmp(v, "best_n")) o.cost_comb = TSAR_COMB_BEST_N;
-            else { printf("Command-line parameter error: Unknown cost combination method\n\n"); usage(); return -1; }   // angle/good: not on the GPU path
+            else if (!strcmp(v, "angle")) o.cost_comb = TSAR_COMB_ANGLE;      // main.cpp:787-790; the kernels treat both as "all" (gipuma.cu:496-499)
+            else if (!strcmp(v, "good")) o.cost_comb = TSAR_COMB_GOOD;
+            else { printf("Command-line parameter error: Unknown cost combination method\n\n"); usage(); return -1; }
         } else if (starts("--cam_scale=")) o.cam_scale = (float)atof(a + 12);
         else if (starts("--depth_min=")) o.depth_min = (float)atof(a + 12);
         else if (starts("--depth_max=")) o.depth_max = (float)atof(a + 12);
