@@ -4,8 +4,8 @@
 //
 // The reference bubble-sorts four (value, weight) lists of up to 121 taps per pixel in 5 kB of
 // per-thread local memory, O(n^2) data-moving swaps.  Here the same sorted order is obtained without
-// moving data: each tap's rank is counted (stable: ties keep tap order) and the lists are walked in
-// rank order.  The reference's sort also touches slot `num` (a zero entry joins and the largest entry
+// moving data: each tap's rank is counted (stable: ties keep tap order) from an LDS copy of the list, and the
+// lists are walked in rank order.  The reference's sort also touches slot `num` (a zero entry joins and the largest entry
 // drops out); that is reproduced by ranking num+1 entries and walking the first num.
 // Neighbours are read from launch-start copies of scale / depth / planes (the reference reads what
 // other threads of the same launch are writing).
@@ -14,34 +14,65 @@
 #define WMF_BLOCK 64
 #define WMF_CAP 146
 
+#define WMF_ROWS 123   // 11 x 11 taps + the zero slot + 1
+
 struct WmfTaps {
     float w[WMF_CAP];
     float d[WMF_CAP], x[WMF_CAP], y[WMF_CAP], z[WMF_CAP];
     int n[WMF_CAP];
-    unsigned char pos[WMF_CAP];
     int num;
 };
 
-// order[r] = index of the entry with stable rank r among entries 0..num (entry num is the zero slot)
-DEVFN void rank_order(const float* v, int num, unsigned char* pos) {
-    for (int k = 0; k <= num; k++) {
-        const float vk = v[k];
-        int r = 0;
-        for (int j = 0; j <= num; j++) {
-            const float vj = v[j];
-            r += (vj < vk) || (vj == vk && j < k);
+// Per-workgroup staging for the O(n^2) ranking: the list being ranked, [entry][thread], and the resulting order.
+// The tap arrays above live in scratch (written once, read O(n) times); ranking them from scratch cost ~120 k scratch
+// loads per pixel (1.04 s per launch at 24 Mpixel), from LDS it is a conflict-free ds_read per comparison.
+struct WmfLds {
+    float v[WMF_ROWS * WMF_BLOCK];
+    unsigned char pos[WMF_ROWS * WMF_BLOCK];
+};
+
+// pos[r] = index of the entry with stable rank r among entries 0..num (entry num is the zero slot).
+// Four entries are ranked per pass over the list: one LDS read feeds four independent compare/add chains.
+DEVFN void rank_order(const float* v, int num, WmfLds& l) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k <= num; k++) l.v[k * WMF_BLOCK + tid] = v[k];
+    for (int k0 = 0; k0 <= num; k0 += 4) {
+        float vk[4];
+        int r[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; c++) vk[c] = l.v[min(k0 + c, num) * WMF_BLOCK + tid];
+        for (int j = 0; j < k0; j++) {                               // entries before all four: ties sort first
+            const float vj = l.v[j * WMF_BLOCK + tid];
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[c] += vj <= vk[c];
         }
-        pos[r] = (unsigned char)k;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {                             // the four themselves
+            const int j = k0 + jj;
+            if (j > num) break;
+            const float vj = l.v[j * WMF_BLOCK + tid];
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[c] += (jj < c) ? (vj <= vk[c]) : ((jj > c) ? (vj < vk[c]) : 0);
+        }
+        for (int j = k0 + 4; j <= num; j++) {                        // entries after all four
+            const float vj = l.v[j * WMF_BLOCK + tid];
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[c] += vj < vk[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (k0 + c <= num) l.pos[r[c] * WMF_BLOCK + tid] = (unsigned char)(k0 + c);
     }
 }
-DEVFN float weighted_median(const float* v, const float* w, const unsigned char* pos, int num, float half) {
+DEVFN int pos_at(const WmfLds& l, int i) { return l.pos[i * WMF_BLOCK + threadIdx.x]; }
+DEVFN float weighted_median(const float* v, const float* w, const WmfLds& l, int num, float half) {
     float acc = 0.f;
     for (int i = 0; i < num; i++) {
-        const int k = pos[i];
+        const int k = pos_at(l, i);
         acc += w[k];
         if (acc >= half) return v[k];
     }
-    return v[pos[num - 1]];
+    return v[pos_at(l, num - 1)];
 }
 
 DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict__ scale_in, const float* __restrict__ depth_in,
@@ -72,29 +103,29 @@ DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict_
 }
 
 // plane through the weighted-median-depth tap with the per-component weighted-median normal
-DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict__ depth_in, WmfTaps& t, float4& out) {
+DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict__ depth_in, WmfTaps& t, WmfLds& l, float4& out) {
     const DevRef& rf = sc->ref;
     const int num = t.num;
-    rank_order(t.d, num, t.pos);
+    rank_order(t.d, num, l);
     float wsum = 0.f;
-    for (int i = 0; i < num; i++) wsum += t.w[t.pos[i]];
+    for (int i = 0; i < num; i++) wsum += t.w[pos_at(l, i)];
     const float half = wsum / 2.f;
     int weimid = -1;
     {
         float acc = 0.f;
         for (int i = 0; i < num; i++) {
-            const int k = t.pos[i];
+            const int k = pos_at(l, i);
             acc += t.w[k];
             if (acc >= half) { weimid = t.n[k]; break; }
         }
     }
     float nm[3];
-    rank_order(t.x, num, t.pos);
-    nm[0] = weighted_median(t.x, t.w, t.pos, num, half);
-    rank_order(t.y, num, t.pos);
-    nm[1] = weighted_median(t.y, t.w, t.pos, num, half);
-    rank_order(t.z, num, t.pos);
-    nm[2] = weighted_median(t.z, t.w, t.pos, num, half);
+    rank_order(t.x, num, l);
+    nm[0] = weighted_median(t.x, t.w, l, num, half);
+    rank_order(t.y, num, l);
+    nm[1] = weighted_median(t.y, t.w, l, num, half);
+    rank_order(t.z, num, l);
+    nm[2] = weighted_median(t.z, t.w, l, num, half);
     if (weimid < 0) return false;
     const float depth_mid = rf.f * rf.baseline / depth_in[weimid];
     const double nrm = (double)sqrtf(dot3(nm, nm));   // `double xyzsqr = sqrtf(..)`, gipuma.cu:1663-1666
@@ -115,10 +146,11 @@ __global__ __launch_bounds__(WMF_BLOCK) void wmf_detect_kernel(const DevScene* _
     const int y = p / w, x = p - y * w;
     const int po = 1 << iter, repo = 1 << (3 - iter);
     const int radius = 80 / po, gap = 16 / po, ths = 24 / po;
+    __shared__ WmfLds lds;
     WmfTaps t;
     float4 nm;
     float s = 0.0f;
-    if (collect_taps(sc, scale_in, depth, n4, x, y, radius, gap, (float)repo, t) > 0 && median_plane(sc, depth, t, nm)) {
+    if (collect_taps(sc, scale_in, depth, n4, x, y, radius, gap, (float)repo, t) > 0 && median_plane(sc, depth, t, lds, nm)) {
         const DevRef& rf = sc->ref;
         const float fb = rf.f * rf.baseline;
         const float disp_now = fb / plane_depth(rf, nm, x, y);
@@ -140,11 +172,12 @@ __global__ __launch_bounds__(WMF_BLOCK) void wmf_fill_kernel(const DevScene* __r
     const int y = p / w, x = p - y * w;
     const int po = 1 << iter;
     const int radius = 5 * po, gap = po, ths = 32 / po;
+    __shared__ WmfLds lds;
     WmfTaps t;
     float4 nm;
     const int num = collect_taps(sc, scale_in, depth_in, n_in, x, y, radius, gap, (float)po, t);
     if (num < ths || num == 0) return;
-    if (!median_plane(sc, depth_in, t, nm)) return;
+    if (!median_plane(sc, depth_in, t, lds, nm)) return;
     const DevRef& rf = sc->ref;
     n_out[p] = nm;
     const float disp = rf.f * rf.baseline / plane_depth(rf, nm, x, y);
