@@ -118,3 +118,82 @@ def test_fusion_cli_reads_what_the_matcher_cli_writes(tmp_path):
     assert n > 1000 and len(body) == n * 27
     rec = np.frombuffer(body, dtype=np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3)]))
     assert np.isfinite(rec["p"]).all() and np.allclose(np.linalg.norm(rec["n"], axis=1), 1, atol=1e-4)
+
+
+def test_weak_png_mask_decoding(tmp_path):
+    """weak.png of the reference's live path (main.cpp:1499-1514): white / pure green / pure red pixels are
+    reliable.  The C++ reader (host/tsar_io.h, zlib) must undo every PNG row filter."""
+    import __graft_entry__ as ge
+    if not os.path.exists(CLI):
+        ge.build()
+    rng = np.random.default_rng(0)
+    h, w = 37, 53
+    rgb = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    m = rng.uniform(size=(h, w))
+    rgb[m < 0.3] = (255, 255, 255)
+    rgb[(m >= 0.3) & (m < 0.4)] = (0, 255, 0)
+    rgb[(m >= 0.4) & (m < 0.5)] = (255, 0, 0)
+    rgb[(m >= 0.5) & (m < 0.6)] = (0, 0, 255)          # pure blue is NOT reliable
+    reliable = np.all(rgb == 255, -1) | np.all(rgb == (0, 255, 0), -1) | np.all(rgb == (255, 0, 0), -1)
+    idx = np.nonzero(reliable.ravel())[0]
+    want = f"mask {w} x {h} reliable {reliable.sum()} checksum {int((idx % 9973).sum())}"
+    for name, filters in (("plain", None), ("filtered", [0, 1, 2, 3, 4]), ("paeth", [4])):
+        p = str(tmp_path / f"{name}.png")
+        tio.write_png(p, rgb, filters=filters)
+        out = subprocess.run([CLI, f"--check-mask={p}"], capture_output=True, text=True).stdout
+        assert want in out, (name, out)
+    g = str(tmp_path / "gray.png")
+    tio.write_reliable_mask(g, reliable)
+    assert want in subprocess.run([CLI, f"--check-mask={g}"], capture_output=True, text=True).stdout
+    open(g, "wb").write(b"not a png")
+    assert "cannot decode" in subprocess.run([CLI, f"--check-mask={g}"], capture_output=True, text=True).stdout
+
+
+@pytest.mark.gpu
+def test_cli_tsar_mode_is_the_reference_live_path(tmp_path):
+    """--mode=tsar: external depth/normal .dmb + weak.png -> weak-texture regions -> region RANSAC -> plane fill ->
+    TSAR_disp.dmb / TSAR_normals.dmb (runGipuma, main.cpp:1458-1860), against the same sequence through the library"""
+    from tsar_mvs_amd import api
+    sc = synth.make_scene(1216, 832, 2, seed=5, textureless=True, flat_cell=3.0)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    h, w = sc.h, sc.w
+    rng = np.random.default_rng(3)
+    textured = sc.textured.numpy()
+    gt = sc.gt_depth.numpy()
+    depth = (gt * (1 + rng.normal(0, 0.002, gt.shape))).astype(np.float32)
+    junk = rng.uniform(sc.depth_min, sc.depth_max, gt.shape).astype(np.float32)
+    good = textured | (rng.uniform(size=gt.shape) < 0.1)                      # the external matcher fails on most flat pixels
+    depth[~good] = junk[~good]
+    normal_world = np.ascontiguousarray((sc.gt_normal.numpy() @ sc.R[0]).astype(np.float32))   # R^T n_cam per pixel
+    apd = root + "APD/00000000/"
+    os.makedirs(apd, exist_ok=True)
+    tio.write_dmb(apd + "depths_geom.dmb", depth)
+    tio.write_dmb(apd + "normals.dmb", normal_world)
+    tio.write_reliable_mask(apd + "weak.png", good)
+    names = [f"{k:08d}.pgm" for k in (0, 1, 2)]
+    cmd = [CLI, *names, "-mslp_folder", root, "-images_folder", root + "images/", "--blocksize=11", "--n_best=1", "--mode=tsar"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got_d = tio.read_dmb(apd + "TSAR_disp.dmb")
+    got_n = tio.read_dmb(apd + "TSAR_normals.dmb")
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max))
+    m.set_views(sc.images, sc.K, sc.R, sc.t)
+    m.set_view_subset(tio.source_slots(0, [1, 2]))
+    m.load_planes(depth, normal_world)
+    m.set_reliable_mask(good.astype(np.float32))
+    labels, text, size = m.detect_weak_texture()
+    m.getview()
+    m.ransac_regions()
+    m.fake_depth()
+    m.fill_textureless()
+    res = m.get_result(("depth", "normal"))
+    assert np.array_equal(got_d, res["depth"]) and np.array_equal(got_n, res["normal"])
+    # and it did something: inside the detected weak regions the junk depth was replaced by a plane close to the truth
+    weak = np.isin(labels, np.nonzero(text == -1)[0]) & ~good
+    assert weak.sum() > 5000
+    err_before = np.abs(depth[weak] - gt[weak]) / gt[weak]
+    err_after = np.abs(res["depth"][weak] - gt[weak]) / gt[weak]
+    assert np.median(err_after) < 0.02 < np.median(err_before)
+    m.close()

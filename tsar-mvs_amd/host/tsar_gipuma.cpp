@@ -10,6 +10,7 @@
 // Fusion reads.  Beyond the reference:
 //   --all [--gpus=N]   process every reference view of pair.txt, dealt round-robin to N GPUs, one host
 //                      thread + one tsar_ctx per GPU (replaces the shell loop)
+//   --mode=tsar is the reference's live path (external planes + weak.png -> region RANSAC -> plane fill);
 //   --mode=patchmatch  (default) random init + iterations; --mode=load starts from
 //                      APD/<id>/depths_geom.dmb + normals.dmb like the reference snapshot (main.cpp:1462-1490)
 //   --seed=S, --strict, --fix-quirks
@@ -61,7 +62,7 @@ static void mkdirs(const std::string& path) {
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
-           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load] [--seed=S] [--strict] [--fix-quirks]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--seed=S] [--strict] [--fix-quirks]\n"
            "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
 
@@ -89,6 +90,16 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         else if (starts("--gpus=")) o.gpus = atoi(a + 7);
         else if (starts("--seed=")) o.seed = strtoull(a + 7, nullptr, 10);
         else if (starts("--mode=")) o.mode = a + 7;
+        else if (starts("--check-mask=")) {          // diagnostics, no GPU: decode a weak.png the way --mode=tsar does
+            std::vector<float> scale;
+            int mw = 0, mh = 0;
+            if (!read_reliable_mask(a + 13, scale, mw, mh)) { printf("cannot decode %s\n", a + 13); return -1; }
+            size_t ones = 0, wsum = 0;
+            for (size_t k = 0; k < scale.size(); k++)
+                if (scale[k] == 1.0f) { ones++; wsum += k % 9973; }
+            printf("mask %d x %d reliable %zu checksum %zu\n", mw, mh, ones, wsum);
+            return 1;
+        }
         else if (!strcmp(a, "--all")) o.all = true;
         else if (!strcmp(a, "--strict")) o.strict = true;
         else if (!strcmp(a, "--fix-quirks")) o.fix_quirks = true;
@@ -150,7 +161,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     const std::string out_dir = o.mslp_folder + "APD/" + stem8(names[0]) + "/";   // main.cpp:1462, 1813-1830
     mkdirs(out_dir);
     const size_t np = (size_t)w * h;
-    if (o.mode == "load") {
+    const bool tsar_mode = o.mode == "tsar";
+    if (o.mode == "load" || tsar_mode) {
         std::vector<float> d, nrm;
         int hh, ww, nb;
         if (!read_dmb(out_dir + "depths_geom.dmb", d, hh, ww, nb) || hh != h || ww != w || nb != 1) { fprintf(stderr, "cannot read %sdepths_geom.dmb\n", out_dir.c_str()); tsar_destroy(ctx); return -1; }
@@ -160,7 +172,23 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         if (tsar_pm_init(ctx) != TSAR_OK) return fail("tsar_pm_init");
         if (tsar_pm_iterate(ctx, o.iterations) != TSAR_OK) return fail("tsar_pm_iterate");
     }
-    if (tsar_compute_disp(ctx) != TSAR_OK) return fail("tsar_compute_disp");
+    if (tsar_mode) {
+        // the reference's live path, runGipuma main.cpp:1493-1783: external planes (above: firstcuda) -> reliability mask
+        // from weak.png -> weak-texture regions of the reference image (texture(), main.cpp:214-596) -> sliccuda
+        // (gipuma_getview) -> per-region plane RANSAC (:1520-1730) -> fakecuda -> fillcuda
+        std::vector<float> scale;
+        int mw = 0, mh = 0;
+        if (!read_reliable_mask(out_dir + "weak.png", scale, mw, mh) || mw != w || mh != h) { fprintf(stderr, "cannot read %sweak.png (8-bit PNG of the image size)\n", out_dir.c_str()); tsar_destroy(ctx); return -1; }
+        if (tsar_set_reliable_mask(ctx, scale.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_set_reliable_mask");
+        int n_regions = 0;
+        if (tsar_detect_weak_texture(ctx, nullptr, TSAR_MEM_HOST, &n_regions, nullptr, nullptr, 0) != TSAR_OK) return fail("tsar_detect_weak_texture");
+        if (tsar_getview(ctx) != TSAR_OK) return fail("tsar_getview");
+        std::vector<float> planes((size_t)4 * (n_regions > 0 ? n_regions : 1)), ratio((size_t)(n_regions > 0 ? n_regions : 1));
+        if (tsar_ransac_regions(ctx, planes.data(), ratio.data()) != TSAR_OK) return fail("tsar_ransac_regions");
+        if (tsar_fake_depth(ctx, nullptr, TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_fake_depth");
+        if (tsar_fill_textureless(ctx) != TSAR_OK) return fail("tsar_fill_textureless");
+        printf("view %08d: %d regions labelled, textureless ones refitted and filled\n", ref_id, n_regions);
+    } else if (tsar_compute_disp(ctx) != TSAR_OK) return fail("tsar_compute_disp");
     std::vector<float> depth(np), normal(3 * np);
     if (tsar_get_result(ctx, depth.data(), normal.data(), nullptr, nullptr, TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_get_result");
     tsar_destroy(ctx);

@@ -3,12 +3,14 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <fstream>
 #include <map>
 #include <string>
 #include <vector>
+#include <zlib.h>
 
 #include "../../include/tsar.h"
 
@@ -96,3 +98,80 @@ static inline bool read_dmb(const std::string& path, std::vector<float>& data, i
     return ok;
 }
 
+// Minimal PNG reader (8-bit gray / RGB / RGBA / palette, non-interlaced) on zlib: the reliability mask of the
+// reference's live path is APD/<id>/weak.png, which it reads with cv::imread(IMREAD_COLOR) (main.cpp:1499-1514).
+// Output: interleaved RGB, 3 bytes per pixel.
+static inline bool read_png_rgb(const std::string& path, std::vector<unsigned char>& rgb, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<unsigned char> file;
+    unsigned char buf[65536];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+    fclose(f);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) return false;
+    auto be32 = [&](size_t o) { return ((uint32_t)file[o] << 24) | ((uint32_t)file[o + 1] << 16) | ((uint32_t)file[o + 2] << 8) | (uint32_t)file[o + 3]; };
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    w = h = 0;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        const uint32_t len = be32(o);
+        if (o + 12 + (size_t)len > file.size()) return false;
+        const char* type = (const char*)&file[o + 4];
+        const unsigned char* data = &file[o + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = (int)be32(o + 8); h = (int)be32(o + 12);
+            depth = data[8]; ctype = data[9]; interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+        else if (!memcmp(type, "IEND", 4)) break;
+        o += 12 + (size_t)len;
+    }
+    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
+    std::vector<unsigned char> img(stride * (size_t)h);
+    for (int y = 0; y < h; y++) {                       // undo the per-row filters (PNG spec 9.2)
+        const unsigned char ft = raw[(stride + 1) * y];
+        const unsigned char* in = &raw[(stride + 1) * y + 1];
+        unsigned char* out = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)ch ? out[i - ch] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)ch) ? up[i - ch] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) { const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else if (ft != 0) return false;
+            out[i] = (unsigned char)(in[i] + pred);
+        }
+    }
+    rgb.resize((size_t)w * h * 3);
+    for (size_t p = 0; p < (size_t)w * h; p++) {
+        const unsigned char* s = &img[p * ch];
+        unsigned char r, g, b;
+        if (ctype == 3) { const size_t k = (size_t)s[0] * 3; if (k + 2 >= plte.size()) return false; r = plte[k]; g = plte[k + 1]; b = plte[k + 2]; }
+        else if (ch <= 2) { r = g = b = s[0]; }
+        else { r = s[0]; g = s[1]; b = s[2]; }
+        rgb[p * 3] = r; rgb[p * 3 + 1] = g; rgb[p * 3 + 2] = b;
+    }
+    return true;
+}
+
+// weak.png -> lines->scale: white, pure green and pure red pixels are reliable (main.cpp:1503-1513; scale starts at 0)
+static inline bool read_reliable_mask(const std::string& path, std::vector<float>& scale, int& w, int& h) {
+    std::vector<unsigned char> rgb;
+    if (!read_png_rgb(path, rgb, w, h)) return false;
+    scale.assign((size_t)w * h, 0.0f);
+    for (size_t p = 0; p < scale.size(); p++) {
+        const unsigned char r = rgb[p * 3], g = rgb[p * 3 + 1], b = rgb[p * 3 + 2];
+        if ((r == 255 && g == 255 && b == 255) || (r == 0 && g == 255 && b == 0) || (r == 255 && g == 0 && b == 0)) scale[p] = 1.0f;
+    }
+    return true;
+}

@@ -134,6 +134,54 @@ def read_pgm(path: str) -> np.ndarray:
     return np.frombuffer(data, np.uint8, count=w * h, offset=pos).reshape(h, w).astype(np.float32)
 
 
+def write_png(path: str, rgb, filters=None) -> None:
+    """8-bit PNG writer (gray [h, w] or RGB [h, w, 3]) on zlib, for the reliability mask APD/<id>/weak.png of the
+    reference's live path (main.cpp:1499).  filters: optional per-row PNG filter types 0..4 (tests of the C++ reader)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(rgb, np.uint8)
+    h, w = a.shape[:2]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    ctype = {1: 0, 3: 2, 4: 6}[ch]
+    rows = a.reshape(h, w * ch).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        ft = 0 if filters is None else int(filters[y % len(filters)])
+        cur = rows[y]
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        ul = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pred = np.zeros_like(cur)
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) // 2
+        else:
+            p = left + prev - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+        raw.append(ft)
+        raw += ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
+
+
+def write_reliable_mask(path: str, reliable) -> None:
+    """weak.png as the reference reads it: white = reliable, black = not (main.cpp:1503-1513)"""
+    m = np.asarray(reliable).astype(bool)
+    rgb = np.zeros(m.shape + (3,), np.uint8)
+    rgb[m] = 255
+    write_png(path, rgb)
+
+
 def convert_image(src: str, dst_pgm: str) -> None:
     """Decode any PIL-readable image as 8-bit gray (ITU-R 601 luma, like cv::IMREAD_GRAYSCALE) -> PGM."""
     from PIL import Image
