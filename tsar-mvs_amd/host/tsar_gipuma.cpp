@@ -25,6 +25,8 @@
 #include <chrono>
 #include <fstream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -38,7 +40,7 @@ struct Options {
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
     bool all = false, strict = false, fix_quirks = false;
-    int gpus = 1;
+    int gpus = 1, workers = 2;      // --all: worker threads per GPU (file I/O of one view overlaps the kernels of another)
     uint64_t seed = 0;
     std::string mode = "patchmatch";
 };
@@ -62,7 +64,7 @@ static void mkdirs(const std::string& path) {
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
-           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--seed=S] [--strict] [--fix-quirks]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks]\n"
            "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
 
@@ -88,6 +90,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         else if (starts("--depth_min=")) o.depth_min = (float)atof(a + 12);
         else if (starts("--depth_max=")) o.depth_max = (float)atof(a + 12);
         else if (starts("--gpus=")) o.gpus = atoi(a + 7);
+        else if (starts("--workers=")) o.workers = atoi(a + 10);
         else if (starts("--seed=")) o.seed = strtoull(a + 7, nullptr, 10);
         else if (starts("--mode=")) o.mode = a + 7;
         else if (starts("--check-mask=")) {          // diagnostics, no GPU: decode a weak.png the way --mode=tsar does
@@ -116,22 +119,43 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
     return 0;
 }
 
+// Decoded images shared by all views of a run (--all visits every image as a reference once and as a source ~N times).
+struct ImageCache {
+    struct Entry { std::vector<float> gray; int w = 0, h = 0; bool ok = false; };
+    std::mutex mu;
+    std::map<std::string, std::shared_ptr<Entry>> items;
+    std::shared_ptr<Entry> get(const std::string& path) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = items.find(path);
+            if (it != items.end()) return it->second;
+        }
+        auto e = std::make_shared<Entry>();                       // decode outside the lock; a rare double decode is harmless
+        e->ok = read_pgm(path, e->gray, e->w, e->h);
+        std::lock_guard<std::mutex> lk(mu);
+        auto ins = items.emplace(path, e);
+        return ins.first->second;
+    }
+};
+static ImageCache g_images;
+
 // one reference view: images[0] is the reference, the rest the candidate sources in argv order
 static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds) {
     const auto t0 = std::chrono::steady_clock::now();
     const int n = (int)names.size();
-    std::vector<std::vector<float>> gray(n);
+    std::vector<std::shared_ptr<ImageCache::Entry>> gray(n);
     std::vector<const float*> ptrs(n);
     std::vector<tsar_camera> cams(n);
     int w = 0, h = 0;
     float dmin = o.depth_min, dmax = o.depth_max;
     for (int i = 0; i < n; i++) {
-        int wi, hi;
         const std::string ip = o.images_folder + pgm_name(names[i]);
-        if (!read_pgm(ip, gray[i], wi, hi)) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); return -1; }
+        gray[i] = g_images.get(ip);
+        if (!gray[i]->ok) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); return -1; }
+        const int wi = gray[i]->w, hi = gray[i]->h;
         if (i == 0) { w = wi; h = hi; }
         if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); return -1; }
-        ptrs[i] = gray[i].data();
+        ptrs[i] = gray[i]->gray.data();
         CamFile cf;
         const std::string cp = o.mslp_folder + "cams/" + stem8(names[i]) + "_cam.txt";
         if (!read_cam(cp, cf)) { fprintf(stderr, "cannot read camera %s\n", cp.c_str()); return -1; }
@@ -215,11 +239,13 @@ int main(int argc, char** argv) {
         std::vector<int> refs;
         for (auto& kv : pairs) refs.push_back(kv.first);
         const int ngpu = o.gpus < 1 ? 1 : o.gpus;
-        std::vector<int> status(ngpu, 0);
+        const int nthr = ngpu * (o.workers < 1 ? 1 : o.workers);   // worker t drives GPU t % ngpu with its own context
+        std::vector<int> status(nthr, 0);
         std::vector<std::thread> th;
-        for (int g = 0; g < ngpu; g++)
-            th.emplace_back([&, g]() {
-                for (size_t k = g; k < refs.size(); k += ngpu) {   // round-robin: every view of a scene costs the same
+        for (int t = 0; t < nthr; t++)
+            th.emplace_back([&, t]() {
+                const int g = t % ngpu;
+                for (size_t k = t; k < refs.size(); k += nthr) {   // round-robin: every view of a scene costs the same
                     const int ref = refs[k];
                     char buf[32];
                     std::vector<std::string> names;
@@ -229,7 +255,7 @@ int main(int argc, char** argv) {
                     double sec = 0;
                     const int rc = run_view(o, g, names, {}, ref, &sec);
                     printf("view %08d on gpu %d: %s (%.2f s)\n", ref, g, rc == 0 ? "ok" : "FAILED", sec);
-                    if (rc != 0) status[g] = rc;   // a failed view does not stop the others
+                    if (rc != 0) status[t] = rc;   // a failed view does not stop the others
                 }
             });
         for (auto& t : th) t.join();
