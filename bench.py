@@ -90,6 +90,29 @@ def cpu_baseline(args):
             "sample": f"{w}x{h} synthetic view, {args.views} src views, {args.iters} iters, box {args.box} (CPU oracle, OpenMP), {dt:.1f}s"}
 
 
+def host_boundary(args, sc):
+    """One step through the C ABI the way a host caller without device pointers uses it: images handed over as host
+    buffers (H2D + quad-texture build inside tsar_set_views), results copied back to host (D2H inside tsar_get_result).
+    Reported next to `value`, never as `value` (which is measured with inputs resident in HBM)."""
+    from tsar_mvs_amd import api
+    w, h = args.width, args.height
+    host_imgs = [im.cpu().numpy() for im in sc.images]
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=args.box, box_vsize=args.box, n_best=args.n_best, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=2024))
+    t0 = time.perf_counter()
+    m.set_views(host_imgs, sc.K, sc.R, sc.t)
+    t1 = time.perf_counter()
+    m.pm_init()
+    m.pm_iterate(args.iters)
+    m.compute_disp()
+    t2 = time.perf_counter()
+    m.get_result(("depth", "normal", "cost"))
+    t3 = time.perf_counter()
+    m.close()
+    return {"value": w * h / (t3 - t0) / 1e6, "unit": "Mpix/s", "set_views_h2d_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3,
+            "get_result_d2h_ms": (t3 - t2) * 1e3, "note": "pageable host buffers in, host buffers out; one view"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +129,7 @@ def main():
     ap.add_argument("--cpu-height", type=int, default=640, dest="cpu_height")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-host-boundary", action="store_true", dest="no_host_boundary")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -204,6 +228,8 @@ def main():
             tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
             line["roofline"]["valu"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flops_per_launch": flops_per_launch}
             line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
+        if world == 1 and not args.no_host_boundary:
+            line["host_boundary"] = host_boundary(args, sc)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
