@@ -5,11 +5,11 @@
 
 #define FULL_RH 8
 
-template <int NB, int HR, bool STRICT, bool QUAD, bool INIT>
+template <int NB, int HR, bool STRICT, bool QUAD, bool INIT, int V = 0>
 __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __restrict__ sc, const float4* __restrict__ planes_in,
                                                            float* __restrict__ c_out, float4* __restrict__ n_out,
                                                            int32_t* __restrict__ beview_out, float* __restrict__ ratio_out, int tiles_x,
-                                                           int n_tiles) {
+                                                           int n_tiles, int strip_w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename TileOf<QUAD>::type TileT;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
@@ -17,7 +17,9 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __res
     TileT* tile = (TileT*)lds_raw;
     float* wts = (float*)(lds_raw + tile_bytes<QUAD>(tw, th)) + threadIdx.x;
     const int t = xcd_tile(blockIdx.x, n_tiles);
-    const int ty0 = (t / tiles_x) * FULL_RH, tx0 = (t % tiles_x) * PM_RW;
+    int tix, tiy;
+    strip_tile(t, tiles_x, n_tiles / tiles_x, strip_w, tix, tiy);
+    const int ty0 = tiy * FULL_RH, tx0 = tix * PM_RW;
     stage_ref_tile<FULL_RH, TileT>(sc, tile, tx0, ty0, hr, vr);
     __syncthreads();
     const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __res
     const PixelRef pr = hoist_reference<HR, TileT>(tile, tw, own, wts, hr, vr);
     float cost = TSAR_MAXCOST, rt = 0.f;
     int bv = -1;
-    if (pr.textured) cost = multiview_cost<NB, HR, STRICT, QUAD>(sc, tile, tw, own, wts, pr, x, y, n4, bv, rt);
+    if (pr.textured) cost = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, n4, bv, rt);
     c_out[p] = cost;
     if (!INIT) {
         if (beview_out) beview_out[p] = bv;
@@ -68,17 +70,17 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __res
     }
 }
 
-template <int NB, int HR, bool STRICT, bool QUAD, bool INIT>
+template <int NB, int HR, bool STRICT, bool QUAD, bool INIT, int V = 0>
 static int launch_full_t(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
     const DevScene& hs = ctx->hscene;
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + FULL_RH - 1) / FULL_RH;
     const int n_tiles = tiles_x * tiles_y;
     const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, FULL_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK;
-    auto kern = pm_full_kernel<NB, HR, STRICT, QUAD, INIT>;
+    auto kern = pm_full_kernel<NB, HR, STRICT, QUAD, INIT, V>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ScopedKernelTimer tm(ctx, INIT ? "pm_init" : "pm_cost_planes");
-        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, planes, c, n, bv, rt, tiles_x, n_tiles);
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, planes, c, n, bv, rt, tiles_x, n_tiles, ctx->strip_w);
     }
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;
@@ -88,6 +90,10 @@ template <int NB, int HR, bool INIT>
 static int launch_full_nh(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
     if (strict) return quad ? launch_full_t<NB, HR, true, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, true, false, INIT>(ctx, planes, c, n, bv, rt);
+    if (quad && NB == 2 && HR == 5) {   // the production configuration uses the sweep's tap-loop variant (pm_core.h view_cost)
+        if (ctx->variant == 10) return launch_full_t<2, 5, false, true, INIT, 10>(ctx, planes, c, n, bv, rt);
+        if (ctx->variant & 2) return launch_full_t<2, 5, false, true, INIT, 2>(ctx, planes, c, n, bv, rt);
+    }
     return quad ? launch_full_t<NB, HR, false, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, false, false, INIT>(ctx, planes, c, n, bv, rt);
 }
 
