@@ -126,3 +126,18 @@ def test_cfg2_full_size_properties():
     c_again, _, _ = m.pm_cost_planes(planes)
     assert np.max(np.abs(c_again - c_host)) <= 2e-3
     m.close()
+
+
+def test_lds_patch_sweep_variant_bit_exact(monkeypatch):
+    """the opt-in LDS-patch form of the sweep (pm_sweep_lds.hip, TSAR_LDS_SWEEP=1): slower than the default kernel
+     but kept as a measured alternative — it must produce the oracle's bits too"""
+    monkeypatch.setenv("TSAR_LDS_SWEEP", "1")
+    sc = synth.make_scene(192, 128, 4, seed=11)
+    orc = _oracle(sc, seed=5)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    m = api.matcher_from_scene(sc, seed=5, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(2)
+    _assert_state_equal(m, orc)
+    m.close()

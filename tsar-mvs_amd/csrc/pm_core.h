@@ -129,7 +129,7 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 
 // pmCost gipuma.cu:229-298 for one source view, given the hoisted reference terms.
 // V selects a code-generation variant of the tap loop (identical arithmetic unless noted):
-//   bit 0: two tap columns per trip (12 gathers in flight per wave instead of 6)
+//   (bit 0, two tap columns per trip, was measured and removed: 135 VGPRs, one wave of occupancy lost)
 //   bit 1: fast mode only — clamp with v_med3_f32 and take the fraction with v_fract_f32
 //          (differs from floor/subtract only for u in (-2^-24, 0), where fract saturates below 1)
 //   bit 2: experiment — no gather (texel bits synthesised from the address): the VALU floor of the kernel
@@ -221,16 +221,8 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             ++tap;
         }
     };
-    if ((V & 1) && HR == 5) {
 #pragma unroll 1
-        for (int i = -5; i <= 5; i += 4) {
-            column(i);
-            column(i + 2);
-        }
-    } else {
-#pragma unroll 1
-        for (int i = -hr; i <= hr; i += 2) column(i);
-    }
+    for (int i = -hr; i <= hr; i += 2) column(i);
     sum_src *= pr.inv_wsum;
     sum_src_src *= pr.inv_wsum;
     sum_ref_src *= pr.inv_wsum;

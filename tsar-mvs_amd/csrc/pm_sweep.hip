@@ -261,9 +261,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     if (strict) return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
     if (quad && NB == 2 && HR == 5) {   // the production configuration: code-generation variants (TSAR_VARIANT)
         switch (ctx->variant) {
-            case 1: return launch_sweep_t<2, 5, false, true, 1>(ctx, colour, a, b, c, sid, dp, dr);
             case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
-            case 3: return launch_sweep_t<2, 5, false, true, 3>(ctx, colour, a, b, c, sid, dp, dr);
             case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
             case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
             default: break;
