@@ -134,6 +134,7 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          (differs from floor/subtract only for u in (-2^-24, 0), where fract saturates below 1)
 //   bit 2: experiment — no gather (texel bits synthesised from the address): the VALU floor of the kernel
 //   bit 3: fast mode, radius 5 — reference-window texels loaded with ds_read_u16_d16_hi (no convert instruction)
+//   (bit 4, a clamp-free loop for waves whose windows project inside the image, was measured: no gain, removed)
 template <int HR, bool STRICT, bool QUAD, int V = 0>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
                       const PixelRef& pr, int x, int y, const float4& n4) {
@@ -145,11 +146,15 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     else plane_homography_fast(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     int tap = 0;
-    auto column = [&](int i) {
+    constexpr bool FAST6 = QUAD && !STRICT && (V & 2) && HR == 5;   // the production tap loop: 8-bit quad texture, radius 5
+    // One window column (six taps) of the production loop, written in three explicit phases — all six tap positions,
+    // then all six gathers, then unpack / blend / accumulate — so that six gathers are in flight per wave whatever
+    // the instruction scheduler decides (it keeps source order when a reordering would cost registers).
+    auto column_fast = [&](int i) {
         const float xi = (float)(x + i);
         const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
         float rcol[6];
-        if (QUAD && !STRICT && (V & 8) && HR == 5) {
+        if (V & 8) {
             // the column's six reference texels, each loaded into bits 31:16 of a register = its fp32 value.  gfx950 runs
             // with SRAM ECC, where a D16 load writes the whole register (zeros in the other half); tsar_create probes
             // this once and falls back to the variant without bit 3 if it does not hold.  The loads are invisible to the
@@ -162,6 +167,60 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             for (int jj = 0; jj < 6; jj++)
                 asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"(jj * 2 * (PM_RW + 10) * 2), "v"(bz));
         }
+        float ax[6], ay[6];
+        uint32_t q[6];
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) {                        // phase 1: tap positions -> byte offsets; phase 2: gathers
+            const float yj = (float)(y + 2 * jj - 5);
+            const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            float u = X * rz, v = Y * rz;
+            u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
+            v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+            ax[jj] = __builtin_amdgcn_fractf(u);
+            ay[jj] = __builtin_amdgcn_fractf(v);
+            int iu, iv;                                         // floor + convert in one instruction each
+            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
+            // byte offset of quad entry (iv + 1, iu + 1): one 24-bit multiply-add, one shift-add; the two +1 are
+            // folded into the uniform constant (qp + 1) * 4
+            int lin;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
+            uint32_t off;
+            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
+            if (V & 4) q[jj] = off * 2654435761u;               // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
+            else q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) {                        // phase 3: unpack, blend, accumulate
+            float t00, t10, t01, t11;                           // the four texels: one convert each, no shifts/masks
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q[jj]));
+            const float top = fma_(ax[jj], t10 - t00, t00);
+            const float bot = fma_(ax[jj], t11 - t01, t01);
+            float s = fma_(ay[jj], bot - top, top);
+            float r;
+            if (V & 8) {
+                // tied to s so that the wait cannot be scheduled ahead of the gather's return, by which time the LDS
+                // loads issued at the top of the column have long completed
+                asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[jj]), "+v"(s));
+                r = rcol[jj];
+            } else {
+                r = tile_value(tile[own + (2 * jj - 5) * tw + i]);
+            }
+            const float ws = wts[(tap + jj) * PM_BLOCK] * s;
+            sum_src += ws;
+            sum_src_src = fma_(ws, s, sum_src_src);
+            sum_ref_src = fma_(ws, r, sum_ref_src);             // (w s) r: one multiply fewer per tap than the oracle's (w r) s
+        }
+        tap += 6;
+    };
+    // any window, both arithmetic modes, float or quad images: one tap at a time in the oracle's order
+    auto column = [&](int i) {
+        const float xi = (float)(x + i);
+        const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
 #pragma unroll
         for (int j = -vr; j <= vr; j += 2) {
             const float yj = (float)(y + j);
@@ -175,54 +234,24 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 u = X * rz;
                 v = Y * rz;
             }
-            float s;
-            if (QUAD && !STRICT && (V & 2)) {
-                u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
-                v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
-                const float ax = __builtin_amdgcn_fractf(u), ay = __builtin_amdgcn_fractf(v);
-                int iu, iv;                                     // floor + convert in one instruction each
-                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
-                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
-                // byte offset of quad entry (iv + 1, iu + 1): one 24-bit multiply-add, one shift-add; the two +1 are
-                // folded into the uniform constant (qp + 1) * 4
-                int lin;
-                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-                uint32_t off;
-                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
-                uint32_t q;
-                if (V & 4) q = off * 2654435761u;             // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
-                else q = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
-                float t00, t10, t01, t11;                       // the four texels: one convert each, no shifts/masks
-                asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q));
-                asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q));
-                asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q));
-                asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q));
-                const float top = fma_(ax, t10 - t00, t00);
-                const float bot = fma_(ax, t11 - t01, t01);
-                s = fma_(ay, bot - top, top);
-            } else {
-                s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
-            }
-            float r;
-            if (QUAD && !STRICT && (V & 8) && HR == 5) {
-                // tied to s so that the wait cannot be scheduled ahead of the gather's return, by which time the LDS
-                // loads issued at the top of the column have long completed
-                asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[(j + 5) >> 1]), "+v"(s));
-                r = rcol[(j + 5) >> 1];
-            } else {
-                r = tile_value(tile[own + j * tw + i]);
-            }
+            const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
+            const float r = tile_value(tile[own + j * tw + i]);
             const float wt = wts[tap * PM_BLOCK];
             const float ws = wt * s;
             sum_src += ws;
             sum_src_src = fma_(ws, s, sum_src_src);
             if (STRICT) sum_ref_src = fma_(wt * r, s, sum_ref_src);      // (w r) s, the oracle's order
-            else sum_ref_src = fma_(ws, r, sum_ref_src);                 // (w s) r: one multiply fewer per tap
+            else sum_ref_src = fma_(ws, r, sum_ref_src);
             ++tap;
         }
     };
+    if (FAST6) {
 #pragma unroll 1
-    for (int i = -hr; i <= hr; i += 2) column(i);
+        for (int i = -5; i <= 5; i += 2) column_fast(i);
+    } else {
+#pragma unroll 1
+        for (int i = -hr; i <= hr; i += 2) column(i);
+    }
     sum_src *= pr.inv_wsum;
     sum_src_src *= pr.inv_wsum;
     sum_ref_src *= pr.inv_wsum;
