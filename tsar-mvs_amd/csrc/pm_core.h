@@ -1,5 +1,5 @@
 // pm_core.h — the matching cost and the per-pixel PatchMatch step, shared by the init / sweep /
-// cost-evaluation kernels (pm_init.hip, pm_sweep.hip, pm_cost.hip).
+// cost-evaluation kernels (pm_init.hip, pm_sweep.hip, pm_sweep_lds.hip).
 //
 // Mapping (MI355X-first): one thread owns one pixel and walks its hypotheses; a
 // 256-thread workgroup owns a 32-wide pixel region.  Per workgroup, once per launch:
@@ -12,7 +12,7 @@
 //   - pixels whose reference window has no texture (var_ref < 1e-5) can never change (every
 //     hypothesis scores MAXCOST, gipuma.cu:289-291) and stop there.
 // Source taps: the homography-warped position is bilinearly sampled in software (no texture unit on
-// gfx950).  For 8-bit imagery each view is pre-packed into 2x2 texel quads (tex_kernels.hip), so a
+// gfx950).  For 8-bit imagery each view is pre-packed into 2x2 texel quads (plane_kernels.hip build_quad_kernel), so a
 // tap is ONE 4-byte gather instead of four.
 #pragma once
 #include "tsar_device_math.h"

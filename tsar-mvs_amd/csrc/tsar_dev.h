@@ -20,7 +20,7 @@ struct DevView {
     float b[3];              // K t
     float pad2_;
     const float* img;        // [h][w] float gray
-    const uint32_t* quad;    // [(h+2)][(w+2)] packed 2x2 texel quads (8-bit images only), see tex_kernels.hip
+    const uint32_t* quad;    // [(h+2)][(w+2)] packed 2x2 texel quads (8-bit images only), see plane_kernels.hip build_quad_kernel
 };
 
 // Reference camera block (camera.h:9-33 for cameras[REFERENCE]).
