@@ -197,3 +197,25 @@ def test_cli_tsar_mode_is_the_reference_live_path(tmp_path):
     err_after = np.abs(res["depth"][weak] - gt[weak]) / gt[weak]
     assert np.median(err_after) < 0.02 < np.median(err_before)
     m.close()
+
+
+@pytest.mark.gpu
+def test_cli_color_processing_matches_on_the_blue_channel(tmp_path):
+    """-color_processing: the reference uploads BGRA float4 textures but its cost fetches tex2D<float>, i.e. the first
+    (blue) channel (gipuma.cu:247,262,265; main.cpp:1427-1447).  PPM in, same outputs as the gray run on that channel."""
+    sc = synth.make_scene(128, 96, 3, seed=5)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    rng = np.random.default_rng(0)
+    for k in range(4):
+        blue = sc.images[k].numpy()
+        rgb = np.stack([rng.integers(0, 256, blue.shape), rng.integers(0, 256, blue.shape), blue], -1)   # R, G are decoys
+        tio.write_ppm(root + f"images/{k:08d}.ppm", rgb)
+    names = [f"{k:08d}.ppm" for k in (1, 0, 2, 3)]
+    common = ["-mslp_folder", root, "-images_folder", root + "images/", "--iterations=2", "--blocksize=11", "--n_best=1", "--seed=7"]
+    out = subprocess.run([CLI, *names, *common, "-color_processing"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d_col = tio.read_dmb(root + "APD/00000001/TSAR_disp.dmb")
+    out = subprocess.run([CLI, *[n.replace(".ppm", ".pgm") for n in names], *common], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert np.array_equal(d_col, tio.read_dmb(root + "APD/00000001/TSAR_disp.dmb"))

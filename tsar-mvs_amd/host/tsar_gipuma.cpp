@@ -39,7 +39,7 @@ struct Options {
     std::string images_folder, mslp_folder, krt_file, output_folder;
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
-    bool all = false, strict = false, fix_quirks = false;
+    bool all = false, strict = false, fix_quirks = false, color = false;
     int gpus = 1, workers = 2;      // --all: worker threads per GPU (file I/O of one view overlaps the kernels of another)
     uint64_t seed = 0;
     std::string mode = "patchmatch";
@@ -48,10 +48,10 @@ struct Options {
 #include "tsar_io.h"
 
 static std::string stem8(const std::string& name) { return name.substr(0, 8); }   // main.cpp:1460
-static std::string pgm_name(const std::string& name) {
+static std::string pnm_name(const std::string& name, const char* want) {
     const size_t dot = name.find_last_of('.');
     const std::string ext = dot == std::string::npos ? "" : name.substr(dot);
-    return (ext == ".pgm") ? name : name.substr(0, dot) + ".pgm";
+    return (ext == want) ? name : name.substr(0, dot) + want;
 }
 static void mkdirs(const std::string& path) {
     std::string cur;
@@ -64,7 +64,7 @@ static void mkdirs(const std::string& path) {
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
-           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [-color_processing]\n"
            "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
 
@@ -110,6 +110,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         else if (!strcmp(a, "-mslp_folder") && i + 1 < argc) o.mslp_folder = argv[++i];
         else if (!strcmp(a, "-krt_file") && i + 1 < argc) o.krt_file = argv[++i];
         else if (!strcmp(a, "-output_folder") && i + 1 < argc) o.output_folder = argv[++i];
+        else if (!strcmp(a, "-color_processing")) o.color = true;      // main.cpp:727,909
         else if (!strcmp(a, "-no_display") || starts("--cost_gamma=") || starts("--min_angle=") || starts("--max_angle=") || starts("--cost_tau_color=") ||
                  starts("--cost_tau_gradient=") || starts("--cost_alpha=") || starts("--max_views=") || starts("--num_img_processed=")) {
             // accepted for script compatibility; these feed cost functions / view selection the GPU path does not use
@@ -131,7 +132,8 @@ struct ImageCache {
             if (it != items.end()) return it->second;
         }
         auto e = std::make_shared<Entry>();                       // decode outside the lock; a rare double decode is harmless
-        e->ok = read_pgm(path, e->gray, e->w, e->h);
+        const bool ppm = path.size() > 4 && path.compare(path.size() - 4, 4, ".ppm") == 0;
+        e->ok = ppm ? read_ppm_channel(path, 2, e->gray, e->w, e->h) : read_pgm(path, e->gray, e->w, e->h);   // colour: blue, see tsar_io.h
         std::lock_guard<std::mutex> lk(mu);
         auto ins = items.emplace(path, e);
         return ins.first->second;
@@ -149,7 +151,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     int w = 0, h = 0;
     float dmin = o.depth_min, dmax = o.depth_max;
     for (int i = 0; i < n; i++) {
-        const std::string ip = o.images_folder + pgm_name(names[i]);
+        const std::string ip = o.images_folder + pnm_name(names[i], o.color ? ".ppm" : ".pgm");
         gray[i] = g_images.get(ip);
         if (!gray[i]->ok) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); return -1; }
         const int wi = gray[i]->w, hi = gray[i]->h;

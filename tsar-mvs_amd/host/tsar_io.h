@@ -77,6 +77,36 @@ static inline bool read_pgm(const std::string& path, std::vector<float>& img, in
     return true;
 }
 
+// Binary PPM (P6), one channel extracted.  -color_processing in the reference uploads float4 (B, G, R, alpha) textures
+// but the matching cost fetches them with tex2D<float> (gipuma.cu:247,262,265), i.e. it matches on the first channel of
+// OpenCV's BGR order: blue.  channel: 0 = R, 1 = G, 2 = B of the PPM.
+static inline bool read_ppm_channel(const std::string& path, int channel, std::vector<float>& img, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int got = 0, vals[3];
+    if (fscanf(f, "%2s", magic) != 1 || strcmp(magic, "P6") != 0) { fclose(f); return false; }
+    while (got < 3) {
+        int c = fgetc(f);
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (c == EOF) { fclose(f); return false; }
+        if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+        ungetc(c, f);
+        if (fscanf(f, "%d", &vals[got]) != 1) { fclose(f); return false; }
+        got++;
+    }
+    fgetc(f);
+    w = vals[0]; h = vals[1];
+    if (vals[2] > 255 || w <= 0 || h <= 0) { fclose(f); return false; }
+    std::vector<unsigned char> raw((size_t)w * h * 3);
+    const bool ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+    fclose(f);
+    if (!ok) return false;
+    img.resize((size_t)w * h);
+    for (size_t i = 0; i < img.size(); i++) img[i] = (float)raw[i * 3 + channel];
+    return true;
+}
+
 static inline bool write_dmb(const std::string& path, const float* data, int h, int w, int nb) {   // fileIoUtils.h:333-381
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { fprintf(stderr, "Error opening file %s\n", path.c_str()); return false; }

@@ -109,6 +109,16 @@ def write_pgm(path: str, gray) -> None:
         f.write(a8.tobytes())
 
 
+def write_ppm(path: str, rgb) -> None:
+    """binary PPM (P6) for `tsar_gipuma -color_processing`, which like the reference matches on the BLUE channel
+    (tex2D<float> on a BGRA float4 texture, gipuma.cu:247,262,265)"""
+    a8 = np.clip(np.rint(np.asarray(rgb)), 0, 255).astype(np.uint8)
+    assert a8.ndim == 3 and a8.shape[2] == 3
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (a8.shape[1], a8.shape[0]))
+        f.write(a8.tobytes())
+
+
 def read_pgm(path: str) -> np.ndarray:
     with open(path, "rb") as f:
         data = f.read()
@@ -182,10 +192,14 @@ def write_reliable_mask(path: str, reliable) -> None:
     write_png(path, rgb)
 
 
-def convert_image(src: str, dst_pgm: str) -> None:
-    """Decode any PIL-readable image as 8-bit gray (ITU-R 601 luma, like cv::IMREAD_GRAYSCALE) -> PGM."""
+def convert_image(src: str, dst: str) -> None:
+    """Decode any PIL-readable image -> PGM (8-bit gray, ITU-R 601 luma like cv::IMREAD_GRAYSCALE) or, when dst ends
+    in .ppm, -> PPM (RGB, for -color_processing)."""
     from PIL import Image
-    write_pgm(dst_pgm, np.asarray(Image.open(src).convert("L"), np.float32))
+    if dst.lower().endswith(".ppm"):
+        write_ppm(dst, np.asarray(Image.open(src).convert("RGB"), np.float32))
+    else:
+        write_pgm(dst, np.asarray(Image.open(src).convert("L"), np.float32))
 
 
 # ---- a whole synthetic scene on disk, laid out like data/TRAIN/<scene>/ ---------------------------------
@@ -207,4 +221,4 @@ if __name__ == "__main__":
     if len(sys.argv) == 4 and sys.argv[1] == "convert":
         convert_image(sys.argv[2], sys.argv[3])
     else:
-        print("usage: python -m tsar_mvs_amd.io convert <image> <out.pgm>")
+        print("usage: python -m tsar_mvs_amd.io convert <image> <out.pgm | out.ppm>")
