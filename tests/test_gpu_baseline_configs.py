@@ -178,3 +178,54 @@ def test_non_integral_images_bit_exact():
     c_ref, _, _ = orc.pm_cost_planes(orc.norm4)
     assert np.max(np.abs(c_fast - c_ref)) <= 2e-3
     f.close()
+
+
+def test_contexts_release_their_device_memory():
+    """create / run / destroy in a loop: device memory returns to the baseline (every buffer is owned by the context)"""
+    sc = synth.make_scene(640, 480, 3, seed=3)
+    torch.cuda.synchronize()
+
+    def cycle():
+        m = api.matcher_from_scene(sc, seed=1)
+        m.pm_init()
+        m.pm_iterate(1)
+        m.lrdiff()
+        m.getview()
+        m.compute_disp()
+        m.get_result()
+        lab = np.zeros((sc.h, sc.w), np.int32)
+        m.set_regions(lab, np.array([1.0], np.float32))
+        m.set_reliable_mask(np.ones((sc.h, sc.w), np.float32))
+        m.wmf(1, False)
+        m.close()
+
+    cycle()                                   # first use pays one-time runtime allocations
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        cycle()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"leaked {(free0 - free1) >> 20} MiB over 12 contexts"
+
+
+def test_two_contexts_on_one_device_from_two_threads():
+    """the CLI's --workers: two host threads, one context each, same GPU, interleaved kernels -> same bits as alone"""
+    import threading
+    sc = synth.make_scene(320, 240, 3, seed=4)
+    ref = api.matcher_from_scene(sc, seed=2)
+    ref.pm_init(); ref.pm_iterate(2)
+    want = ref.get_plane()
+    ref.close()
+    got = [None, None]
+
+    def work(k):
+        m = api.matcher_from_scene(sc, seed=2)
+        m.pm_init(); m.pm_iterate(2)
+        got[k] = m.get_plane()
+        m.close()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got[k], want))
