@@ -15,6 +15,8 @@
 // gfx950).  For 8-bit imagery each view is pre-packed into 2x2 texel quads (plane_kernels.hip build_quad_kernel), so a
 // tap is ONE 4-byte gather instead of four.
 #pragma once
+#include <type_traits>
+
 #include "tsar_device_math.h"
 
 #define PM_BLOCK 256
@@ -134,7 +136,7 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          (differs from floor/subtract only for u in (-2^-24, 0), where fract saturates below 1)
 //   bit 2: experiment — no gather (texel bits synthesised from the address): the VALU floor of the kernel
 //   bit 3: fast mode, radius 5 — reference-window texels loaded with ds_read_u16_d16_hi (no convert instruction)
-//   (bit 4, a clamp-free loop for waves whose windows project inside the image, was measured: no gain, removed)
+//   bit 4: fast mode, radius 5 — clamp-free tap loop for waves whose windows project inside the source image (-1 %)
 template <int HR, bool STRICT, bool QUAD, int V = 0>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
                       const PixelRef& pr, int x, int y, const float4& n4) {
@@ -147,10 +149,27 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     int tap = 0;
     constexpr bool FAST6 = QUAD && !STRICT && (V & 2) && HR == 5;   // the production tap loop: 8-bit quad texture, radius 5
+    // Variant bit 4: if the four corner taps of every active lane's window land inside the source image with Z > 0
+    // (the window then maps into the convex quadrilateral they span), no tap needs the clamp and the wave runs a tap
+    // loop without the two v_med3_f32.  Wave-uniform decision, identical results.
+    bool need_clamp = true;
+    if (FAST6 && (V & 16)) {
+        bool inside = true;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float xi = (float)(x + ((c & 1) ? 5 : -5)), yj = (float)(y + ((c & 2) ? 5 : -5));
+            const float X = fma_(H[1], yj, fma_(H[0], xi, H[2])), Y = fma_(H[4], yj, fma_(H[3], xi, H[5])), Z = fma_(H[7], yj, fma_(H[6], xi, H[8]));
+            const float rz = __builtin_amdgcn_rcpf(Z);
+            const float u = X * rz, v = Y * rz;
+            inside = inside && Z > 0.0f && u >= 0.0f && u <= (float)(w - 1) && v >= 0.0f && v <= (float)(h - 1);
+        }
+        need_clamp = !__all(inside);
+    }
     // One window column (six taps) of the production loop, written in three explicit phases — all six tap positions,
     // then all six gathers, then unpack / blend / accumulate — so that six gathers are in flight per wave whatever
     // the instruction scheduler decides (it keeps source order when a reordering would cost registers).
-    auto column_fast = [&](int i) {
+    auto column_fast = [&](int i, auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
         const float xi = (float)(x + i);
         const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
         float rcol[6];
@@ -175,8 +194,10 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
             const float rz = __builtin_amdgcn_rcpf(Z);
             float u = X * rz, v = Y * rz;
-            u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
-            v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+            if (CLAMP) {
+                u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
+                v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+            }
             ax[jj] = __builtin_amdgcn_fractf(u);
             ay[jj] = __builtin_amdgcn_fractf(v);
             int iu, iv;                                         // floor + convert in one instruction each
@@ -191,6 +212,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             if (V & 4) q[jj] = off * 2654435761u;               // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
             else q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
         }
+        if (V & 16) __builtin_amdgcn_sched_barrier(0);           // nothing of phase 3 may move above the last gather
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;                           // the four texels: one convert each, no shifts/masks
@@ -246,8 +268,13 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         }
     };
     if (FAST6) {
+        if (need_clamp) {
 #pragma unroll 1
-        for (int i = -5; i <= 5; i += 2) column_fast(i);
+            for (int i = -5; i <= 5; i += 2) column_fast(i, std::true_type());
+        } else {
+#pragma unroll 1
+            for (int i = -5; i <= 5; i += 2) column_fast(i, std::false_type());
+        }
     } else {
 #pragma unroll 1
         for (int i = -hr; i <= hr; i += 2) column(i);

@@ -91,7 +91,7 @@ static int launch_full_nh(tsar_ctx* ctx, const float4* planes, float* c, float4*
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
     if (strict) return quad ? launch_full_t<NB, HR, true, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, true, false, INIT>(ctx, planes, c, n, bv, rt);
     if (quad && NB == 2 && HR == 5) {   // the production configuration uses the sweep's tap-loop variant (pm_core.h view_cost)
-        if (ctx->variant == 10) return launch_full_t<2, 5, false, true, INIT, 10>(ctx, planes, c, n, bv, rt);
+        if (ctx->variant & 8) return launch_full_t<2, 5, false, true, INIT, 10>(ctx, planes, c, n, bv, rt);
         if (ctx->variant & 2) return launch_full_t<2, 5, false, true, INIT, 2>(ctx, planes, c, n, bv, rt);
     }
     return quad ? launch_full_t<NB, HR, false, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, false, false, INIT>(ctx, planes, c, n, bv, rt);

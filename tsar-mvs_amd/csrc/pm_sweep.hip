@@ -264,6 +264,8 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
             case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
             case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
+            case 18: return launch_sweep_t<2, 5, false, true, 18>(ctx, colour, a, b, c, sid, dp, dr);
+            case 26: return launch_sweep_t<2, 5, false, true, 26>(ctx, colour, a, b, c, sid, dp, dr);
             default: break;
         }
     }
