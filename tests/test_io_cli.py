@@ -219,3 +219,51 @@ def test_cli_color_processing_matches_on_the_blue_channel(tmp_path):
     out = subprocess.run([CLI, *[n.replace(".ppm", ".pgm") for n in names], *common], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert np.array_equal(d_col, tio.read_dmb(root + "APD/00000001/TSAR_disp.dmb"))
+
+
+@pytest.mark.gpu
+def test_cli_display_outputs(tmp_path):
+    """--display_outputs: TSAR_normals.png (16-bit, n * 32767 + 32767, displayUtils.h:239-245) and TSAR_model.ply (one
+    vertex per pixel: world point, world normal, gray x3; displayUtils.h:78-150)"""
+    import struct
+    import zlib
+    sc = synth.make_scene(96, 64, 2, seed=5)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    names = [f"{k:08d}.pgm" for k in (0, 1, 2)]
+    out = subprocess.run([CLI, *names, "-mslp_folder", root, "-images_folder", root + "images/", "--iterations=2", "--blocksize=11", "--n_best=1",
+                          "--display_outputs"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    apd = root + "APD/00000000/"
+    depth, normal = tio.read_dmb(apd + "TSAR_disp.dmb"), tio.read_dmb(apd + "TSAR_normals.dmb")
+    h, w = depth.shape
+    raw = open(apd + "TSAR_normals.png", "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) & 0xffffffff == struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0]
+        if tag == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (w, h, 16, 2, 0, 0, 0)
+    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 6)
+    assert (px[:, 0] == 0).all()
+    vis = px[:, 1:].reshape(h, w, 3, 2).astype(np.int32)
+    vis = vis[..., 0] * 256 + vis[..., 1]
+    want = np.clip(np.rint(normal.astype(np.float32) * np.float32(32767) + np.float32(32767)), 0, 65535).astype(np.int32)
+    assert np.abs(vis - want).max() <= 1
+    ply = open(apd + "TSAR_model.ply", "rb").read()
+    head, body = ply.split(b"end_header\n", 1)
+    assert f"element vertex {w * h}".encode() in head and len(body) == w * h * 27
+    rec = np.frombuffer(body, dtype=np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3)])).reshape(w, h)   # column by column
+    K, R, t = sc.K[0].astype(np.float64), sc.R[0].astype(np.float64), sc.t[0].astype(np.float64)
+    ys, xs = np.mgrid[0:h, 0:w]
+    cam = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs, float)], -1) * depth[..., None] - t
+    world = cam @ R                                            # R^T c per pixel
+    assert np.allclose(rec["p"].transpose(1, 0, 2), world, atol=1e-4)
+    assert np.array_equal(rec["n"].transpose(1, 0, 2), normal)
+    assert np.array_equal(rec["c"][..., 0].T, sc.images[0].numpy().astype(np.uint8))

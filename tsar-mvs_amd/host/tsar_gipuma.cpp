@@ -25,6 +25,7 @@
 #include <chrono>
 #include <fstream>
 #include <map>
+#include <math.h>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -39,7 +40,7 @@ struct Options {
     std::string images_folder, mslp_folder, krt_file, output_folder;
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
-    bool all = false, strict = false, fix_quirks = false, color = false;
+    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false;
     int gpus = 1, workers = 2;      // --all: worker threads per GPU (file I/O of one view overlaps the kernels of another)
     uint64_t seed = 0;
     std::string mode = "patchmatch";
@@ -64,7 +65,7 @@ static void mkdirs(const std::string& path) {
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
-           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [-color_processing]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [-color_processing] [--display_outputs]\n"
            "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
 
@@ -111,6 +112,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         else if (!strcmp(a, "-krt_file") && i + 1 < argc) o.krt_file = argv[++i];
         else if (!strcmp(a, "-output_folder") && i + 1 < argc) o.output_folder = argv[++i];
         else if (!strcmp(a, "-color_processing")) o.color = true;      // main.cpp:727,909
+        else if (!strcmp(a, "--display_outputs")) o.display_outputs = true;   // TSAR_normals.png + TSAR_model.ply (main.cpp:1800-1838)
         else if (!strcmp(a, "-no_display") || starts("--cost_gamma=") || starts("--min_angle=") || starts("--max_angle=") || starts("--cost_tau_color=") ||
                  starts("--cost_tau_gradient=") || starts("--cost_alpha=") || starts("--max_views=") || starts("--num_img_processed=")) {
             // accepted for script compatibility; these feed cost functions / view selection the GPU path does not use
@@ -220,6 +222,15 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     tsar_destroy(ctx);
     if (!write_dmb(out_dir + "TSAR_disp.dmb", depth.data(), h, w, 1)) return -1;
     if (!write_dmb(out_dir + "TSAR_normals.dmb", normal.data(), h, w, 3)) return -1;
+    if (o.display_outputs) {   // the reference always writes these two; here on request (a full-size view's PLY is 0.66 GB)
+        std::vector<uint16_t> vis(3 * np);
+        for (size_t k = 0; k < 3 * np; k++) {
+            const float v = normal[k] * 32767.f + 32767.f;               // convertTo(CV_16U, 32767, 32767): saturate + round
+            vis[k] = (uint16_t)(v <= 0.f ? 0 : v >= 65535.f ? 65535 : (int)lrintf(v));
+        }
+        if (!write_png_rgb16(out_dir + "TSAR_normals.png", vis.data(), w, h)) return -1;
+        if (!write_view_ply(out_dir + "TSAR_model.ply", depth.data(), normal.data(), gray[0]->gray.data(), w, h, cams[0])) return -1;
+    }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (seconds) *seconds = sec;
     FILE* rf = fopen((out_dir + "TSAR_results.txt").c_str(), "a");   // main.cpp:1854-1860

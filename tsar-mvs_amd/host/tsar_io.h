@@ -1,6 +1,7 @@
 // tsar_io.h — the reference's on-disk formats for the C++ host tools (SURVEY §8b process-level contract):
 // cams/%08d_cam.txt (fileIoUtils.h:117-153), pair.txt (main.cpp:1351-1376), .dmb (fileIoUtils.h:260-381), binary PGM.
 #pragma once
+#include <float.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -192,6 +193,68 @@ static inline bool read_png_rgb(const std::string& path, std::vector<unsigned ch
         rgb[p * 3] = r; rgb[p * 3 + 1] = g; rgb[p * 3 + 2] = b;
     }
     return true;
+}
+
+// 16-bit RGB PNG writer (zlib), for TSAR_normals.png: the reference shows world normals as n * 32767 + 32767 per channel
+// (getNormalsForDisplay, displayUtils.h:239-245, then imwrite of the BGR-swapped image: x -> R, y -> G, z -> B in the file).
+static inline bool write_png_rgb16(const std::string& path, const uint16_t* rgb, int w, int h) {
+    std::vector<unsigned char> raw((size_t)h * (1 + (size_t)w * 6));
+    for (int y = 0; y < h; y++) {
+        unsigned char* row = &raw[(size_t)y * (1 + (size_t)w * 6)];
+        row[0] = 0;                                          // filter type none
+        for (int k = 0; k < w * 3; k++) { const uint16_t v = rgb[(size_t)y * w * 3 + k]; row[1 + 2 * k] = (unsigned char)(v >> 8); row[2 + 2 * k] = (unsigned char)(v & 255); }
+    }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 1) != Z_OK) return false;
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto chunk = [&](const char* tag, const unsigned char* data, uint32_t len) {
+        unsigned char hdr[8] = {(unsigned char)(len >> 24), (unsigned char)(len >> 16), (unsigned char)(len >> 8), (unsigned char)len, (unsigned char)tag[0], (unsigned char)tag[1], (unsigned char)tag[2], (unsigned char)tag[3]};
+        fwrite(hdr, 1, 8, f);
+        if (len) fwrite(data, 1, len, f);
+        uLong crc = crc32(0L, hdr + 4, 4);
+        if (len) crc = crc32(crc, data, len);
+        const unsigned char c[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8), (unsigned char)crc};
+        fwrite(c, 1, 4, f);
+    };
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    const unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w, (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h, 16, 2, 0, 0, 0};
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32_t)clen);
+    chunk("IEND", nullptr, 0);
+    return fclose(f) == 0;
+}
+
+// TSAR_model.ply: one vertex per pixel — world point of the depth, world normal, gray three times (storePlyFileBinary,
+// displayUtils.h:78-150; X = R^T (depth K^-1 (x, y, 1) - t), cameraGeometryUtils.h:53-65; non-finite points become 0).
+// The reference writes the vertices from an OpenMP loop in arbitrary order; here column by column as its loop nest reads.
+static inline bool write_view_ply(const std::string& path, const float* depth, const float* normal, const float* gray, int w, int h, const tsar_camera& cam) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+               "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", w * h);
+    const double fx = cam.K[0], sk = cam.K[1], cx = cam.K[2], fy = cam.K[4], cy = cam.K[5];
+    std::vector<unsigned char> col((size_t)h * 27);
+    for (int x = 0; x < w; x++) {
+        for (int y = 0; y < h; y++) {
+            const size_t p = (size_t)y * w + x;
+            const double d = depth[p];
+            const double yc = (y - cy) / fy, xc = (x - cx - sk * yc) / fx;           // K^-1 (x, y, 1), K upper triangular
+            const double c[3] = {d * xc - cam.t[0], d * yc - cam.t[1], d - cam.t[2]};
+            float rec[6];
+            for (int k = 0; k < 3; k++) rec[k] = (float)(cam.R[k] * c[0] + cam.R[3 + k] * c[1] + cam.R[6 + k] * c[2]);   // R^T c
+            if (!(rec[0] < FLT_MAX && rec[0] > -FLT_MAX && rec[1] < FLT_MAX && rec[1] > -FLT_MAX && rec[2] < FLT_MAX && rec[2] > -FLT_MAX)) rec[0] = rec[1] = rec[2] = 0.f;
+            rec[3] = normal[p * 3]; rec[4] = normal[p * 3 + 1]; rec[5] = normal[p * 3 + 2];
+            unsigned char* o = &col[(size_t)y * 27];
+            memcpy(o, rec, 24);
+            const float g = gray[p];
+            o[24] = o[25] = o[26] = (unsigned char)(g < 0.f ? 0 : g > 255.f ? 255 : (int)g);
+        }
+        if (fwrite(col.data(), 1, col.size(), f) != col.size()) { fclose(f); return false; }
+    }
+    return fclose(f) == 0;
 }
 
 // weak.png -> lines->scale: white, pure green and pure red pixels are reliable (main.cpp:1503-1513; scale starts at 0)
