@@ -91,11 +91,46 @@ DEVFN int block_count(const float* __restrict__ pts, int n, double a, double b, 
     return tot;
 }
 
+// The same count for RS_BATCH planes in one pass over the points: the hypotheses between two threshold adaptations
+// are independent of each other (only their counts are compared afterwards, in order), so a batch shares the point
+// loads (600 KB per region per pass, from L2) and the two barriers.
+#define RS_BATCH 8
+DEVFN void block_count_batch(const float* __restrict__ pts, int n, const double (*pl)[4], int nb, double thr, int (*shb)[RS_BATCH], int* out) {
+    int cnt[RS_BATCH];
+#pragma unroll
+    for (int q = 0; q < RS_BATCH; q++) cnt[q] = 0;
+    for (int i = threadIdx.x; i < n; i += RS_BLOCK) {
+        const double px = (double)pts[3 * i], py = (double)pts[3 * i + 1], pz = (double)pts[3 * i + 2];
+#pragma unroll
+        for (int q = 0; q < RS_BATCH; q++) {
+            const double resid = fabs(px * pl[q][0] + py * pl[q][1] + pz * pl[q][2] + pl[q][3]);
+            cnt[q] += resid < thr;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RS_BATCH; q++)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt[q] += __shfl_down(cnt[q], o);
+    __syncthreads();                       // previous readers of shb are done
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < RS_BATCH; q++) shb[threadIdx.x >> 6][q] = cnt[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_BATCH; q++) {
+        int tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < RS_BLOCK / 64; wv++) tot += shb[wv][q];
+        out[q] = tot;
+    }
+}
+
 __global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
                                                               const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
                                                               const float* __restrict__ region_size, uint32_t k0, uint32_t k1, uint32_t flags,
                                                               float4* __restrict__ region_n4, float* __restrict__ inlier_ratio) {
     __shared__ int sh[RS_BLOCK / 64];
+    __shared__ int shb[RS_BLOCK / 64][RS_BATCH];
     const int slot = blockIdx.x;
     const int rg = region_of_slot[slot];
     const int n = pts_count[slot];
@@ -106,7 +141,8 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __res
         // `float depth_abs = 0.0003 * sqrtf(size / 20)` main.cpp:1551-1552
         float depth_abs_f = (float)(0.0003 * (double)sqrtf(region_size[rg] / 20));
         double depth_abs = depth_abs_f;
-        for (int k = 0; k < 10000; k++) {                                   // main.cpp:1603-1662
+        // hypothesis k of main.cpp:1603-1640: three Philox-drawn points -> unit plane (calcLinePara main.cpp:147-164)
+        auto hypothesis = [&](int k, double* pl) {
             uint32_t r[4];
             philox_raw((uint32_t)k, 0x52414E53u, (uint32_t)rg, k0, k1, r);
             const float* p1 = pts + 3 * rnd_index(r[0], (uint32_t)n);
@@ -119,10 +155,15 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __res
             double tc = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1);
             double td = -(ta * x1 + tb * y1 + tc * z1);
             const double sq = sqrt(ta * ta + tb * tb + tc * tc);
-            ta /= sq; tb /= sq; tc /= sq; td /= sq;
-            const int cnt = block_count(pts, n, ta, tb, tc, td, depth_abs, sh);
-            if (cnt >= maximum) { a = ta; b = tb; c = tc; d = td; maximum = cnt; }
-            if (k % 1000 == 0) {                                            // adaptive inlier threshold, main.cpp:1642-1661
+            pl[0] = ta / sq; pl[1] = tb / sq; pl[2] = tc / sq; pl[3] = td / sq;
+        };
+        for (int k = 0; k < 10000;) {                                       // main.cpp:1603-1662
+            if (k % 1000 == 0) {
+                double pl[4];
+                hypothesis(k, pl);
+                const int cnt = block_count(pts, n, pl[0], pl[1], pl[2], pl[3], depth_abs, sh);
+                if (cnt >= maximum) { a = pl[0]; b = pl[1]; c = pl[2]; d = pl[3]; maximum = cnt; }
+                // adaptive inlier threshold, main.cpp:1642-1661
                 const double rat = (double)maximum / (double)n;
                 if (rat < 0.3 && depth_abs < 0.003) {
                     depth_abs_f = (float)((double)depth_abs_f + 0.0001);
@@ -135,6 +176,18 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __res
                         maximum = max2;
                     }
                 }
+                k++;
+            } else {                                                        // up to the next adaptation the threshold is fixed
+                const int nb = min(RS_BATCH, 1000 - k % 1000);
+                double pl[RS_BATCH][4];
+                int cnt[RS_BATCH];
+#pragma unroll
+                for (int q = 0; q < RS_BATCH; q++) hypothesis(k + (q < nb ? q : 0), pl[q]);
+                block_count_batch(pts, n, pl, nb, depth_abs, shb, cnt);
+#pragma unroll
+                for (int q = 0; q < RS_BATCH; q++)
+                    if (q < nb && cnt[q] >= maximum) { a = pl[q][0]; b = pl[q][1]; c = pl[q][2]; d = pl[q][3]; maximum = cnt[q]; }
+                k += nb;
             }
         }
         for (int round = 0; round < 1000; round++) {                        // local perturbation, main.cpp:1667-1711
