@@ -342,6 +342,15 @@ DEVFN void strip_tile(int t, int tiles_x, int tiles_y, int sw, int& tx, int& ty)
     tx = strip * sw + within - ty * width;
 }
 
+// Strip width: the tile list is cut into 8 contiguous chunks, one per XCD (xcd_tile); with strips of ceil(tiles_x / 8)
+// tiles every XCD walks (almost exactly) one vertical band of the image, so the L2s hold disjoint parts of the source
+// views.  Measured at 6048 x 4032 (189 tiles across): 24 -> 41.25 ms per sweep, 16 -> 41.9, 32 -> 42.0, 48 -> 42.4.
+static inline int strip_width(int requested, int tiles_x) {
+    if (requested >= 0) return requested;
+    const int sw = (tiles_x + 7) / 8;
+    return sw < 8 ? 8 : sw;
+}
+
 DEVFN int xcd_tile(int bid, int n) {
     const int chunk = n >> 3, rem = n & 7;
     const int xcd = bid & 7, slot = bid >> 3;

@@ -80,7 +80,7 @@ static int launch_full_t(tsar_ctx* ctx, const float4* planes, float* c, float4* 
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ScopedKernelTimer tm(ctx, INIT ? "pm_init" : "pm_cost_planes");
-        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, planes, c, n, bv, rt, tiles_x, n_tiles, ctx->strip_w);
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, planes, c, n, bv, rt, tiles_x, n_tiles, strip_width(ctx->strip_w, tiles_x));
     }
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;

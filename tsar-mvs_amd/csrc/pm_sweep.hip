@@ -249,7 +249,7 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
         ScopedKernelTimer tm(ctx, "pm_sweep");
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
                            other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles,
-                           ctx->cost_consistent ? 1 : 0, ctx->strip_w);
+                           ctx->cost_consistent ? 1 : 0, strip_width(ctx->strip_w, tiles_x));
     }
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;
