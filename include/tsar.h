@@ -89,6 +89,8 @@ extern "C" {
                                                   (reference comparison is inverted, gipuma.cu:943) */
 #define TSAR_FLAG_STRICT_DIV         (1u << 2) /* IEEE divisions in the per-tap perspective divide
                                                   (bit-exact against the CPU oracle; slower) */
+#define TSAR_FLAG_NO_LINE_CLOSING    (1u << 4) /* tsar_detect_weak_texture: skip the Hough boundary closing of large regions
+                                                  (main.cpp:385-435; on by default like the reference's HoughLinesP step) */
 
 typedef struct tsar_ctx tsar_ctx;
 

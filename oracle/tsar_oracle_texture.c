@@ -7,8 +7,9 @@
  *   cv::pyrDown  -> restated from its published definition: 5x5 separable kernel [1 4 6 4 1]/16 per axis,
  *                   BORDER_REFLECT_101, output (w/2, h/2) sampled at even source pixels, 8-bit result
  *                   rounded as (sum + 128) >> 8;
- *   cv::HoughLinesP + cv::line (boundary closing of large regions, main.cpp:391-435) -> NOT restated: it is
- *                   a randomised OpenCV-internal algorithm; the step is skipped (documented deviation).
+ *   cv::HoughLinesP + cv::line (boundary closing of large regions, main.cpp:391-435) -> a randomised OpenCV-internal
+ *                   algorithm that cannot be restated; replaced by a deterministic Hough transform with the same
+ *                   parameters (orc_hough_close below; documented deviation, parity unpinned for this step).
  * Everything else is restated literally, including: the uchar wrap of (uchar)sqrt(t1+t2) for gradient
  * magnitudes >= 256 (x86 truncation), `const int sizerat = 2.5` (== 2), and Connect()'s parent
  * overwrite `connection[larger] = smaller`, which can lose an earlier link (orc_connect_literal).  The
@@ -174,4 +175,105 @@ void orc_upsample_labels(const int32_t *lab4, int w4, int h4, int w, int h, int3
             if (syp >= h4) syp--;
             out[(size_t)y * w + x] = lab4[(size_t)syp * w4 + sxp];
         }
+}
+
+/* ---- boundary closing of large regions (main.cpp:385-435) -------------------------------------------------
+ * The reference finds long straight pieces of each large region's boundary with cv::HoughLinesP(rho 1, theta 1 deg,
+ * threshold Houthr = 110, minLineLength = 160, maxLineGap = 18; :60-62, :425) and draws them into the edge image
+ * with cv::line, so that the second labelling cannot leak through gaps in a straight edge.  HoughLinesP is a
+ * randomised OpenCV-internal algorithm (not in the reference tree): PARITY UNPINNED for this step.
+ * What is built instead is a deterministic Hough transform with the same parameters:
+ *   boundary(L)  = pixels not labelled L that have a 4-neighbour labelled L (main.cpp:393-421, literal);
+ *   votes        acc[theta][rho], theta = 0..179 deg, rho = rint(x cos + y sin) (fp32 tables, fp32 arithmetic);
+ *   lines        cells with acc >= 110 that are local maxima (> left / upper neighbour, >= right / lower one);
+ *   segments     walk the line across the image along its major axis, one pixel per step; a run of boundary pixels
+ *                ends when more than maxLineGap consecutive steps miss; it is kept when its end points differ by
+ *                >= minLineLength in x or in y (OpenCV's good_line test); kept runs are drawn with an 8-connected
+ *                Bresenham line.
+ * lab0: labels of orc_connect_true on the edge image BEFORE the border fix; edge is modified in place. */
+#define ORC_HOUGH_THR 110
+#define ORC_HOUGH_MINLEN 160
+#define ORC_HOUGH_MAXGAP 18
+#define ORC_WEAK_COUNT 5000
+
+void orc_hough_tables(float *cs, float *sn) {          /* 180 entries each */
+    for (int t = 0; t < 180; t++) {
+        const double a = (double)t * 3.14159265358979323846 / 180.0;
+        cs[t] = (float)cos(a);
+        sn[t] = (float)sin(a);
+    }
+}
+static void draw_line8(uint8_t *img, int w, int h, int x0, int y0, int x1, int y1) {
+    int dx = abs(x1 - x0), sx = x0 < x1 ? 1 : -1;
+    int dy = -abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (;;) {
+        if (x0 >= 0 && x0 < w && y0 >= 0 && y0 < h) img[(size_t)y0 * w + x0] = 255;
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x0 += sx; }
+        if (e2 <= dx) { err += dx; y0 += sy; }
+    }
+}
+/* one Hough cell -> segments; returns the number drawn */
+static int walk_line(const uint8_t *bmask, uint8_t *edge, int w, int h, float c, float s, float rho) {
+    const int xmajor = fabsf(s) >= fabsf(c);            /* the line is closer to horizontal: step in x */
+    const int n = xmajor ? w : h;
+    int run = 0, sx = 0, sy = 0, lx = 0, ly = 0, gap = 0, drawn = 0;
+    for (int k = 0; k <= n; k++) {
+        int on = 0, x = 0, y = 0;
+        if (k < n) {
+            if (xmajor) { x = k; y = (int)lrintf((rho - (float)x * c) / s); }
+            else        { y = k; x = (int)lrintf((rho - (float)y * s) / c); }
+            on = x >= 0 && x < w && y >= 0 && y < h && bmask[(size_t)y * w + x] != 0;
+        }
+        if (on) {
+            if (!run) { run = 1; sx = x; sy = y; }
+            lx = x; ly = y; gap = 0;
+        } else if (run && (++gap > ORC_HOUGH_MAXGAP || k == n)) {
+            if (abs(lx - sx) >= ORC_HOUGH_MINLEN || abs(ly - sy) >= ORC_HOUGH_MINLEN) { draw_line8(edge, w, h, sx, sy, lx, ly); drawn++; }
+            run = 0; gap = 0;
+        }
+    }
+    return drawn;
+}
+/* returns the number of segments drawn into edge */
+int orc_hough_close(uint8_t *edge, const int32_t *lab0, int labelnum0, int w, int h) {
+    const size_t np = (size_t)w * h;
+    int32_t *count = (int32_t *)calloc((size_t)labelnum0, sizeof(int32_t));
+    for (size_t p = 0; p < np; p++) count[lab0[p]]++;
+    float cs[180], sn[180];
+    orc_hough_tables(cs, sn);
+    const int rmax = w + h + 2, nrho = 2 * rmax + 1;
+    int32_t *acc = (int32_t *)malloc((size_t)180 * nrho * sizeof(int32_t));
+    uint8_t *bmask = (uint8_t *)malloc(np);
+    int drawn = 0;
+    for (int L = 1; L < labelnum0; L++) {
+        if (count[L] <= ORC_WEAK_COUNT) continue;        /* weaklabel0: labelcnt > weaktextnum (main.cpp:356-361) */
+        memset(bmask, 0, np);
+        memset(acc, 0, (size_t)180 * nrho * sizeof(int32_t));
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const size_t p = (size_t)y * w + x;
+                if (lab0[p] == L) continue;
+                if ((x > 0 && lab0[p - 1] == L) || (x < w - 1 && lab0[p + 1] == L) || (y > 0 && lab0[p - w] == L) || (y < h - 1 && lab0[p + w] == L)) {
+                    bmask[p] = 255;
+                    for (int t = 0; t < 180; t++) {
+                        const int r = (int)lrintf((float)x * cs[t] + (float)y * sn[t]);
+                        acc[(size_t)t * nrho + r + rmax]++;
+                    }
+                }
+            }
+        for (int t = 0; t < 180; t++)
+            for (int r = 0; r < nrho; r++) {
+                const int32_t v = acc[(size_t)t * nrho + r];
+                if (v < ORC_HOUGH_THR) continue;
+                const int32_t left = r > 0 ? acc[(size_t)t * nrho + r - 1] : 0, right = r < nrho - 1 ? acc[(size_t)t * nrho + r + 1] : 0;
+                const int32_t up = t > 0 ? acc[(size_t)(t - 1) * nrho + r] : 0, down = t < 179 ? acc[(size_t)(t + 1) * nrho + r] : 0;
+                if (!(v > left && v >= right && v > up && v >= down)) continue;
+                drawn += walk_line(bmask, edge, w, h, cs[t], sn[t], (float)(r - rmax));
+            }
+    }
+    free(count); free(acc); free(bmask);
+    return drawn;
 }

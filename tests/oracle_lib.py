@@ -331,8 +331,10 @@ def slic(bgra, spixel_size=20, iters=5, weight=5.0, connectivity=0, color_space=
 
 
 # ---- weak-texture detection (oracle/tsar_oracle_texture.c) ---------------------------------------------
-def weak_texture(gray_u8, connect="true"):
-    """CPU restatement of texture(): -> dict(labels4, labels, text, size, cenx, ceny, count, edge)"""
+def weak_texture(gray_u8, connect="true", close_lines=False):
+    """CPU restatement of texture(): -> dict(labels4, labels, text, size, cenx, ceny, count, edge).
+    close_lines: run the deterministic Hough boundary closing (orc_hough_close) between the first labelling and the
+    border fix, where the reference calls cv::HoughLinesP (main.cpp:385-435)."""
     L = lib()
     g = np.ascontiguousarray(gray_u8, np.uint8)
     h, w = g.shape
@@ -344,17 +346,23 @@ def weak_texture(gray_u8, connect="true"):
     L.orc_pyrdown(_p(d2), w2, h2, _p(d4))
     edge = np.empty((h4, w4), np.uint8)
     L.orc_roberts_threshold(_p(d4), w4, h4, _p(edge))
-    L.orc_border_fix(_p(edge), w4, h4)
-    lab4 = np.empty((h4, w4), np.int32)
     fn = L.orc_connect_true if connect == "true" else L.orc_connect_literal
     fn.restype = C.c_int
+    segments = 0
+    if close_lines:
+        lab0 = np.empty((h4, w4), np.int32)
+        n0 = L.orc_connect_true(_p(edge), w4, h4, _p(lab0), None, 0)
+        L.orc_hough_close.restype = C.c_int
+        segments = L.orc_hough_close(_p(edge), _p(lab0), n0, w4, h4)
+    L.orc_border_fix(_p(edge), w4, h4)
+    lab4 = np.empty((h4, w4), np.int32)
     n = fn(_p(edge), w4, h4, _p(lab4), None, 0)
     text = np.empty(n, np.float32); size = np.empty(n, np.float32)
     cenx = np.empty(n, np.int32); ceny = np.empty(n, np.int32); count = np.empty(n, np.int32)
     L.orc_region_stats(_p(lab4), w4, h4, n, _p(text), _p(size), _p(cenx), _p(ceny), _p(count))
     labels = np.empty((h, w), np.int32)
     L.orc_upsample_labels(_p(lab4), w4, h4, w, h, _p(labels))
-    return dict(labels4=lab4, labels=labels, text=text, size=size, cenx=cenx, ceny=ceny, count=count, edge=edge, down4=d4)
+    return dict(labels4=lab4, labels=labels, text=text, size=size, cenx=cenx, ceny=ceny, count=count, edge=edge, down4=d4, segments=segments)
 
 
 # ---- fusion (oracle/tsar_oracle_fusion.c) ----------------------------------------------------------------

@@ -393,19 +393,49 @@ def _weak_scene(w=1216, h=832):
 
 def test_weak_texture_detection_matches_oracle():
     sc = _weak_scene()
-    ref = ol.weak_texture(sc.images[0].numpy().astype(np.uint8), connect="true")
-    m = api.matcher_from_scene(sc)
-    labels, text, size = m.detect_weak_texture()
-    assert np.array_equal(labels, ref["labels"])
-    assert np.array_equal(text, ref["text"]) and np.array_equal(size, ref["size"])
-    assert (text == -1).sum() >= 1                     # the flat patches are found ...
-    weak_px = np.isin(labels, np.nonzero(text == -1)[0])
-    flat = ~sc.textured.numpy()
-    assert (weak_px & flat).sum() > 0.5 * weak_px.sum()  # ... and they are mostly the constant-albedo areas
+    for flags, close in ((0, True), (api.FLAG_NO_LINE_CLOSING, False)):
+        ref = ol.weak_texture(sc.images[0].numpy().astype(np.uint8), connect="true", close_lines=close)
+        m = api.matcher_from_scene(sc, flags=flags)
+        labels, text, size = m.detect_weak_texture()
+        assert np.array_equal(labels, ref["labels"])
+        assert np.array_equal(text, ref["text"]) and np.array_equal(size, ref["size"])
+        assert (text == -1).sum() >= 1                     # the flat patches are found ...
+        weak_px = np.isin(labels, np.nonzero(text == -1)[0])
+        flat = ~sc.textured.numpy()
+        assert (weak_px & flat).sum() > 0.5 * weak_px.sum()  # ... and they are mostly the constant-albedo areas
+        m.close()
     # the reference's own two-pass labelling (with its lossy parent overwrite) gives the same partition here
+    ref = ol.weak_texture(sc.images[0].numpy().astype(np.uint8), connect="true")
     lit = ol.weak_texture(sc.images[0].numpy().astype(np.uint8), connect="literal")
     assert len(lit["text"]) >= len(ref["text"])
-    m.close()
+
+
+def test_line_closing_separates_regions_that_leak_through_a_gap():
+    """two flat areas joined through a 40-pixel gap in a straight textured stripe: one region without the boundary
+    closing, two with it (what the reference's HoughLinesP step is for, main.cpp:385-435); GPU == oracle in both modes"""
+    import torch
+    w, h = 1600, 1200
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(h, w)).astype(np.uint8)
+    img[100:1100, 80:780] = 120
+    img[100:1100, 820:1520] = 120
+    img[580:620, 780:820] = 120
+    K = np.array([[900.0, 0, w / 2], [0, 900.0, h / 2], [0, 0, 1]], np.float32)
+    Ks, Rs = np.stack([K, K]), np.stack([np.eye(3, dtype=np.float32)] * 2)
+    ts = np.array([[0, 0, 0], [-0.2, 0, 0]], np.float32)
+    big = {}
+    for flags, close in ((0, True), (api.FLAG_NO_LINE_CLOSING, False)):
+        ref = ol.weak_texture(img, connect="true", close_lines=close)
+        m = api.Matcher()
+        m.set_params(api.default_params(depth_min=1.0, depth_max=10.0, flags=flags))
+        m.set_views([torch.from_numpy(img.astype(np.float32))] * 2, Ks, Rs, ts)
+        labels, text, size = m.detect_weak_texture()
+        assert np.array_equal(labels, ref["labels"]) and np.array_equal(text, ref["text"]) and np.array_equal(size, ref["size"])
+        big[close] = int((ref["count"][1:] > 40000).sum())
+        if close:
+            assert ref["segments"] > 0
+        m.close()
+    assert big[False] == 1 and big[True] == 2
 
 
 # ---- row N3: fusion ----------------------------------------------------------------------------------------

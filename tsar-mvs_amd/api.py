@@ -20,6 +20,7 @@ TSAR_ERR_INVALID, TSAR_ERR_HIP, TSAR_ERR_STATE, TSAR_ERR_NOMEM = -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
 COMB_ALL, COMB_BEST_N, COMB_ANGLE, COMB_GOOD = 0, 1, 2, 3
 FLAG_FIX_DOWN_FAR_SEED, FLAG_FIX_RIGHT_FAR_CMP, FLAG_STRICT_DIV = 1, 2, 4
+FLAG_NO_LINE_CLOSING = 16
 MAXCOST = 2.0
 MAX_VIEWS = 64
 

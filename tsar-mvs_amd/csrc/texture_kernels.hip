@@ -113,6 +113,87 @@ __global__ void tx_ccl_flatten_kernel(const uint8_t* __restrict__ img, int* pare
     parent[p] = r;                                         // concurrent readers still reach the same root: r <= old parent chain
     is_root[p] = (r == p) ? 1 : 0;
 }
+// ---- boundary closing of large regions (main.cpp:385-435) ------------------------------------------------------
+// The reference closes gaps in long straight region boundaries with cv::HoughLinesP + cv::line before the final
+// labelling.  HoughLinesP is randomised and OpenCV-internal; this is a deterministic Hough transform with the same
+// parameters (rho 1, theta 1 deg, threshold 110, minLineLength 160, maxLineGap 18; main.cpp:60-62,425), defined in
+// oracle/tsar_oracle_texture.c orc_hough_close and reproduced here operation for operation.  Parity unpinned.
+#define TX_HOUGH_THR 110
+#define TX_HOUGH_MINLEN 160
+#define TX_HOUGH_MAXGAP 18
+#define TX_WEAK_COUNT 5000
+#define TX_MAX_WEAK 1024
+
+__global__ void tx_root_count_kernel(const int* __restrict__ root, int* __restrict__ cnt, int n) {
+    const int p = blockIdx.x * TX_BLOCK + threadIdx.x;
+    if (p < n && root[p] >= 0) atomicAdd(&cnt[root[p]], 1);
+}
+__global__ void tx_weak_roots_kernel(const int* __restrict__ cnt, int n, int* __restrict__ list, int* __restrict__ nlist) {
+    const int p = blockIdx.x * TX_BLOCK + threadIdx.x;
+    if (p < n && cnt[p] > TX_WEAK_COUNT) {
+        const int k = atomicAdd(nlist, 1);
+        if (k < TX_MAX_WEAK) list[k] = p;
+    }
+}
+// boundary(L): pixels not in component L with a 4-neighbour in it (main.cpp:393-421); every boundary pixel votes
+__global__ void tx_hough_vote_kernel(const int* __restrict__ root, int L, int w, int h, const float* __restrict__ cs, const float* __restrict__ sn,
+                                     uint8_t* __restrict__ bmask, int* __restrict__ acc, int nrho, int rmax) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= w || y >= h) return;
+    const int p = y * w + x;
+    if (root[p] == L) return;
+    if (!((x > 0 && root[p - 1] == L) || (x < w - 1 && root[p + 1] == L) || (y > 0 && root[p - w] == L) || (y < h - 1 && root[p + w] == L))) return;
+    bmask[p] = 255;
+    for (int t = 0; t < 180; t++) {
+        const int r = (int)lrintf((float)x * cs[t] + (float)y * sn[t]);
+        atomicAdd(&acc[(size_t)t * nrho + r + rmax], 1);
+    }
+}
+__device__ void tx_draw_line8(uint8_t* img, int w, int h, int x0, int y0, int x1, int y1) {
+    const int dx = abs(x1 - x0), sx = x0 < x1 ? 1 : -1;
+    const int dy = -abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (;;) {
+        if (x0 >= 0 && x0 < w && y0 >= 0 && y0 < h) img[(size_t)y0 * w + x0] = 255;
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x0 += sx; }
+        if (e2 <= dx) { err += dx; y0 += sy; }
+    }
+}
+// one thread per accumulator cell: local maxima above the threshold are walked across the image and their long
+// runs of boundary pixels drawn into the edge image (idempotent writes of 255)
+__global__ void tx_hough_segments_kernel(const int* __restrict__ acc, int nrho, int rmax, const float* __restrict__ cs, const float* __restrict__ sn,
+                                         const uint8_t* __restrict__ bmask, uint8_t* edge, int w, int h) {
+    const int r = blockIdx.x * TX_BLOCK + threadIdx.x, t = blockIdx.y;
+    if (r >= nrho) return;
+    const int v = acc[(size_t)t * nrho + r];
+    if (v < TX_HOUGH_THR) return;
+    const int left = r > 0 ? acc[(size_t)t * nrho + r - 1] : 0, right = r < nrho - 1 ? acc[(size_t)t * nrho + r + 1] : 0;
+    const int up = t > 0 ? acc[(size_t)(t - 1) * nrho + r] : 0, down = t < 179 ? acc[(size_t)(t + 1) * nrho + r] : 0;
+    if (!(v > left && v >= right && v > up && v >= down)) return;
+    const float c = cs[t], s = sn[t], rho = (float)(r - rmax);
+    const bool xmajor = fabsf(s) >= fabsf(c);
+    const int n = xmajor ? w : h;
+    int run = 0, sx = 0, sy = 0, lx = 0, ly = 0, gap = 0;
+    for (int k = 0; k <= n; k++) {
+        bool on = false;
+        int x = 0, y = 0;
+        if (k < n) {
+            if (xmajor) { x = k; y = (int)lrintf((rho - (float)x * c) / s); }
+            else        { y = k; x = (int)lrintf((rho - (float)y * s) / c); }
+            on = x >= 0 && x < w && y >= 0 && y < h && bmask[(size_t)y * w + x] != 0;
+        }
+        if (on) {
+            if (!run) { run = 1; sx = x; sy = y; }
+            lx = x; ly = y; gap = 0;
+        } else if (run && (++gap > TX_HOUGH_MAXGAP || k == n)) {
+            if (abs(lx - sx) >= TX_HOUGH_MINLEN || abs(ly - sy) >= TX_HOUGH_MINLEN) tx_draw_line8(edge, w, h, sx, sy, lx, ly);
+            run = 0; gap = 0;
+        }
+    }
+}
+
 // label = 1 + number of roots before this pixel's root in raster order; statistics with integer atomics
 __global__ void tx_label_stats_kernel(const int* __restrict__ root, const int* __restrict__ root_rank, int32_t* __restrict__ lab, int w, int h,
                                       int* __restrict__ count, int* __restrict__ sumx, int* __restrict__ sumy, int* __restrict__ xmin,
@@ -186,6 +267,44 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
         hipLaunchKernelGGL(tx_pyrdown_kernel, grid2(w2, h2), b, 0, st, g0, w, h, g2);
         hipLaunchKernelGGL(tx_pyrdown_kernel, grid2(w4, h4), b, 0, st, g2, w2, h2, g4);
         hipLaunchKernelGGL(tx_roberts_kernel, grid2(w4, h4), b, 0, st, g4, w4, h4, edge);
+    }
+    if (!(ctx->hscene.flags & TSAR_FLAG_NO_LINE_CLOSING)) {
+        // first labelling (before the border fix) -> large components -> close gaps in their straight boundaries
+        int* cnt0 = (int*)dmalloc((size_t)n4 * 4);
+        int* wlist = (int*)dmalloc((size_t)TX_MAX_WEAK * 4 + 4);
+        const int rmax = w4 + h4 + 2, nrho = 2 * rmax + 1;
+        int* acc = (int*)dmalloc((size_t)180 * nrho * 4);
+        uint8_t* bmask = (uint8_t*)dmalloc(n4);
+        float* tabs = (float*)dmalloc(360 * 4);
+        if (!cnt0 || !wlist || !acc || !bmask || !tabs) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+        float htab[360];
+        for (int t = 0; t < 180; t++) {
+            const double a = (double)t * 3.14159265358979323846 / 180.0;
+            htab[t] = (float)cos(a);
+            htab[180 + t] = (float)sin(a);
+        }
+        ScopedKernelTimer tm(ctx, "weak_texture_closing");
+        hipMemcpyAsync(tabs, htab, sizeof htab, hipMemcpyHostToDevice, st);
+        hipMemsetAsync(cnt0, 0, (size_t)n4 * 4, st);
+        hipMemsetAsync(wlist, 0, (size_t)TX_MAX_WEAK * 4 + 4, st);
+        hipLaunchKernelGGL(tx_ccl_init_kernel, dim3((n4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, parent, n4);
+        hipLaunchKernelGGL(tx_ccl_merge_kernel, grid2(w4, h4), b, 0, st, edge, parent, w4, h4);
+        hipLaunchKernelGGL(tx_ccl_flatten_kernel, dim3((n4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, parent, is_root, n4);
+        hipLaunchKernelGGL(tx_root_count_kernel, dim3((n4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, parent, cnt0, n4);
+        hipLaunchKernelGGL(tx_weak_roots_kernel, dim3((n4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, cnt0, n4, wlist + 1, wlist);
+        std::vector<int> hl(TX_MAX_WEAK + 1);
+        hipMemcpyAsync(hl.data(), wlist, (size_t)TX_MAX_WEAK * 4 + 4, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "weak-texture kernels failed");
+        const int nweak = hl[0] < TX_MAX_WEAK ? hl[0] : TX_MAX_WEAK;
+        for (int k = 0; k < nweak; k++) {                     // independent of each other: masks come from the first labelling
+            hipMemsetAsync(acc, 0, (size_t)180 * nrho * 4, st);
+            hipMemsetAsync(bmask, 0, (size_t)n4, st);
+            hipLaunchKernelGGL(tx_hough_vote_kernel, grid2(w4, h4), b, 0, st, parent, hl[1 + k], w4, h4, tabs, tabs + 180, bmask, acc, nrho, rmax);
+            hipLaunchKernelGGL(tx_hough_segments_kernel, dim3((nrho + TX_BLOCK - 1) / TX_BLOCK, 180), b, 0, st, acc, nrho, rmax, tabs, tabs + 180, bmask, edge, w4, h4);
+        }
+    }
+    {
+        ScopedKernelTimer tm(ctx, "weak_texture_label");
         hipLaunchKernelGGL(tx_border_rows_kernel, dim3((h4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, w4, h4);
         hipLaunchKernelGGL(tx_border_cols_kernel, dim3((w4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, w4, h4);
         hipLaunchKernelGGL(tx_ccl_init_kernel, dim3((n4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, parent, n4);
