@@ -482,3 +482,37 @@ def test_fusion_of_ground_truth_maps_lands_on_the_surfaces():
     depths[0][:] = 0
     z = ol.fuse(depths, normals, grays, sc.K, sc.R, sc.t, pairs, num_consistent=2)
     assert not (z[:, 8] == 0).any()
+
+
+def test_hough_closing_known_answers():
+    """oracle of the boundary-closing step (deterministic stand-in for the reference's HoughLinesP, main.cpp:385-435):
+    a horizontal boundary with a 10-pixel hole is closed by one line through the hole; a 30-pixel hole (> maxLineGap 18)
+    and a short boundary (< minLineLength 160) are left alone"""
+    import ctypes as C
+    L = ol.lib()
+    L.orc_hough_close.restype = C.c_int
+    L.orc_connect_true.restype = C.c_int
+
+    def run(hole, length):
+        w, h = 400, 220
+        edge = np.zeros((h, w), np.uint8)
+        edge[0, :] = edge[-1, :] = 255
+        edge[:, 0] = edge[:, -1] = 255
+        x0 = (w - length) // 2
+        edge[110, x0:x0 + length] = 255                     # a straight edge between two large flat areas
+        edge[110, :x0] = 255 if length == w else edge[110, :x0]
+        edge[110, 200:200 + hole] = 0                       # the hole
+        lab0 = np.empty((h, w), np.int32)
+        n0 = L.orc_connect_true(ol._p(edge), w, h, ol._p(lab0), None, 0)
+        before = edge.copy()
+        drawn = L.orc_hough_close(ol._p(edge), ol._p(lab0), n0, w, h)
+        return drawn, before, edge
+
+    drawn, before, after = run(10, 400)
+    assert drawn >= 1 and (after[110, 200:210] == 255).all()       # hole closed
+    assert (after >= before).all()                                   # closing only adds edge pixels
+    drawn, before, after = run(30, 400)
+    assert (after[110, 205:225] == 0).any()                          # a gap wider than maxLineGap is not bridged
+    drawn, before, after = run(10, 120)
+    assert np.array_equal(before, after) and (after[110, 200:210] == 0).all()   # a run shorter than minLineLength is not bridged
+                                                                                  # (the frame's own long lines are re-drawn onto themselves)
