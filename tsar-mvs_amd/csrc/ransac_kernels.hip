@@ -131,6 +131,7 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __res
                                                               float4* __restrict__ region_n4, float* __restrict__ inlier_ratio) {
     __shared__ int sh[RS_BLOCK / 64];
     __shared__ int shb[RS_BLOCK / 64][RS_BATCH];
+    __shared__ double shpl[RS_BATCH][4];
     const int slot = blockIdx.x;
     const int rg = region_of_slot[slot];
     const int n = pts_count[slot];
@@ -181,9 +182,20 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __res
                 const int nb = min(RS_BATCH, 1000 - k % 1000);
                 double pl[RS_BATCH][4];
                 int cnt[RS_BATCH];
+                // one thread per hypothesis of the batch builds its plane (three dependent point loads, a double sqrt and
+                // four divisions: ~3 us of latency each if every thread did all eight in turn), then all threads pick them up
+                if (threadIdx.x < RS_BATCH) {
+                    double mine[4];
+                    hypothesis(k + ((int)threadIdx.x < nb ? (int)threadIdx.x : 0), mine);
 #pragma unroll
-                for (int q = 0; q < RS_BATCH; q++) hypothesis(k + (q < nb ? q : 0), pl[q]);
-                block_count_batch(pts, n, pl, nb, depth_abs, shb, cnt);
+                    for (int e = 0; e < 4; e++) shpl[threadIdx.x][e] = mine[e];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < RS_BATCH; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pl[q][e] = shpl[q][e];
+                block_count_batch(pts, n, pl, nb, depth_abs, shb, cnt);     // its two barriers order these reads before the next batch's writes
 #pragma unroll
                 for (int q = 0; q < RS_BATCH; q++)
                     if (q < nb && cnt[q] >= maximum) { a = pl[q][0]; b = pl[q][1]; c = pl[q][2]; d = pl[q][3]; maximum = cnt[q]; }
