@@ -266,6 +266,8 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
             case 18: return launch_sweep_t<2, 5, false, true, 18>(ctx, colour, a, b, c, sid, dp, dr);
             case 26: return launch_sweep_t<2, 5, false, true, 26>(ctx, colour, a, b, c, sid, dp, dr);
+            case 50: return launch_sweep_t<2, 5, false, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
+            case 58: return launch_sweep_t<2, 5, false, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
             default: break;
         }
     }

@@ -184,7 +184,7 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TSAR_ERR_HIP; }
     tsar_default_params(&ctx->params);
     if (const char* e = getenv("TSAR_LDS_SWEEP")) ctx->lds_sweep = e[0] == '1';
-    ctx->variant = probe_d16_hi_zeroes(ctx) ? 26 : 18;
+    ctx->variant = probe_d16_hi_zeroes(ctx) ? 58 : 50;
     if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
     if (const char* e = getenv("TSAR_STRIP")) ctx->strip_w = atoi(e);
     if (const char* e = getenv("TSAR_DEBUG_COUNTERS"))
