@@ -229,3 +229,28 @@ def test_two_contexts_on_one_device_from_two_threads():
         t.join()
     for k in range(2):
         assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got[k], want))
+
+
+def test_random_shapes_bit_exact():
+    """a fixed pseudo-random list of image sizes, view counts, windows and best-N settings: init + one full iteration"""
+    rng = np.random.default_rng(2024)
+    for case in range(10):
+        w, h = int(rng.integers(40, 300)), int(rng.integers(30, 200))
+        n_src = int(rng.integers(1, 7))
+        box = int(rng.choice([5, 7, 9, 11, 13]))
+        n_best = int(rng.integers(1, 4))
+        comb = int(rng.integers(0, 2))
+        flags = int(rng.choice([0, api.FLAG_FIX_DOWN_FAR_SEED | api.FLAG_FIX_RIGHT_FAR_CMP]))
+        sc = synth.make_scene(w, h, n_src, seed=100 + case)
+        orc = _oracle(sc, seed=case, box=box, n_best=n_best, cost_comb=comb, flags=flags)
+        orc.pm_init()
+        orc.pm_iterate(1)
+        m = api.matcher_from_scene(sc, seed=case, box=box, n_best=n_best, cost_comb=comb, flags=flags | api.FLAG_STRICT_DIV)
+        m.pm_init()
+        m.pm_iterate(1)
+        planes, cost, bv, rt = m.get_plane()
+        ctx = (case, w, h, n_src, box, n_best, comb, flags)
+        assert np.array_equal(cost, orc.c), ctx
+        assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32)), ctx
+        assert np.array_equal(bv, orc.beview), ctx
+        m.close()
