@@ -151,7 +151,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:                      # a torch without the device_id keyword
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
