@@ -242,7 +242,8 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
     const DevScene& hs = ctx->hscene;
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
     const int n_tiles = tiles_x * tiles_y;
-    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK;
+    static const size_t lds_pad = getenv("TSAR_LDS_PAD") ? (size_t)atoi(getenv("TSAR_LDS_PAD")) : 0;   // occupancy experiments: unused LDS per workgroup
+    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK + lds_pad;
     auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD, V>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
