@@ -150,7 +150,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     else plane_homography_fast(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     int tap = 0;
-    constexpr bool FAST6 = QUAD && !STRICT && (V & 2) && HR == 5;   // the production tap loop: 8-bit quad texture, radius 5
+    constexpr bool FAST6 = QUAD && (V & 2) && HR == 5;   // the production tap loop: 8-bit quad texture, radius 5 (both arithmetic modes)
     // Variant bit 4: if the four corner taps of every active lane's window land inside the source image with Z > 0
     // (the window then maps into the convex quadrilateral they span), no tap needs the clamp and the wave runs a tap
     // loop without the two v_med3_f32.  Wave-uniform decision, identical results.
@@ -195,17 +195,33 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         for (int jj = 0; jj < 6; jj++) {                        // phase 1: tap positions -> byte offsets; phase 2: gathers
             const float yj = (float)(y + 2 * jj - 5);
             const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
-            const float rz = __builtin_amdgcn_rcpf(Z);
-            float u = X * rz, v = Y * rz;
-            if (CLAMP) {
-                u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
-                v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+            float u, v;
+            int iu, iv;
+            if (STRICT) {                                       // the oracle's operations: IEEE divides, min/max clamp, floor / subtract
+                u = X / Z;
+                v = Y / Z;
+                if (CLAMP) {
+                    u = fminf(fmaxf(u, -1.0f), (float)w);
+                    v = fminf(fmaxf(v, -1.0f), (float)h);
+                }
+                const float fu = floorf(u), fv = floorf(v);
+                ax[jj] = u - fu;
+                ay[jj] = v - fv;
+                iu = (int)fu;
+                iv = (int)fv;
+            } else {
+                const float rz = __builtin_amdgcn_rcpf(Z);
+                u = X * rz;
+                v = Y * rz;
+                if (CLAMP) {
+                    u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
+                    v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+                }
+                ax[jj] = __builtin_amdgcn_fractf(u);
+                ay[jj] = __builtin_amdgcn_fractf(v);
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));   // floor + convert in one instruction each
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
             }
-            ax[jj] = __builtin_amdgcn_fractf(u);
-            ay[jj] = __builtin_amdgcn_fractf(v);
-            int iu, iv;                                         // floor + convert in one instruction each
-            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
-            asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
             // byte offset of quad entry (iv + 1, iu + 1): one 24-bit multiply-add, one shift-add; the two +1 are
             // folded into the uniform constant (qp + 1) * 4
             int lin;
@@ -236,10 +252,12 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             } else {
                 r = tile_value(tile[own + (2 * jj - 5) * tw + i]);
             }
-            const float ws = wts[(tap + jj) * PM_BLOCK] * s;
+            const float wt = wts[(tap + jj) * PM_BLOCK];
+            const float ws = wt * s;
             sum_src += ws;
             sum_src_src = fma_(ws, s, sum_src_src);
-            sum_ref_src = fma_(ws, r, sum_ref_src);             // (w s) r: one multiply fewer per tap than the oracle's (w r) s
+            if (STRICT) sum_ref_src = fma_(wt * r, s, sum_ref_src);   // (w r) s, the oracle's order
+            else sum_ref_src = fma_(ws, r, sum_ref_src);              // (w s) r: one multiply fewer per tap
         }
         tap += 6;
     };

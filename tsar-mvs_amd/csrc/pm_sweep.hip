@@ -259,7 +259,13 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
 template <int NB, int HR>
 static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
-    if (strict) return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
+    if (strict) {
+        // the production tap loop also exists in the oracle's arithmetic (IEEE divides, min/max, floor): same bits as the
+        // generic strict kernel, with the D16 window loads, the clamp-free loop and the gather-phase priority
+        if (quad && NB == 2 && HR == 5 && ctx->variant == 58) return launch_sweep_t<2, 5, true, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
+        if (quad && NB == 2 && HR == 5 && ctx->variant == 50) return launch_sweep_t<2, 5, true, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
+        return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
+    }
     if (quad && NB == 2 && HR == 5) {   // the production configuration: code-generation variants (TSAR_VARIANT)
         switch (ctx->variant) {
             case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
