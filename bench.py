@@ -69,6 +69,19 @@ def traffic_from_profiles(args=None):
     return 2.0 * vals["fetch"] + vals["write"]
 
 
+def available_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a container
+    16 of its 256 hardware threads through cpu.max; 128 OpenMP threads on that quota only thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args):
     """The CPU oracle (kind "port": the reference has no CPU path) on a bounded sample of the same
     workload: same view count / window / iterations, smaller image."""
@@ -78,11 +91,13 @@ def cpu_baseline(args):
     w, h = args.cpu_width, args.cpu_height
     sc = synth.make_scene(w, h, args.views, seed=1234, step=args.cam_step)
     orc = ol.Oracle([im.numpy() for im in sc.images], sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, box=args.box, n_best=args.n_best)
+    cores = available_cpus()
     try:
         omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(cores)                 # same runtime instance the oracle library uses
         cores = int(omp.omp_get_max_threads())
     except OSError:
-        cores = os.cpu_count() or 1
+        pass
     t0 = time.perf_counter()
     orc.pm_init()
     orc.pm_iterate(args.iters)
