@@ -110,24 +110,63 @@ def cpu_baseline(args):
 def host_boundary(args, sc):
     """One step through the C ABI the way a host caller without device pointers uses it: images handed over as host
     buffers (H2D + quad-texture build inside tsar_set_views), results copied back to host (D2H inside tsar_get_result).
-    Reported next to `value`, never as `value` (which is measured with inputs resident in HBM)."""
+    Reported next to `value`, never as `value` (which is measured with inputs resident in HBM).  Two legs: the caller's
+    buffers page-locked (tsar_host_alloc — what tsar_gipuma does) and plain pageable memory."""
     from tsar_mvs_amd import api
     w, h = args.width, args.height
-    host_imgs = [im.cpu().numpy() for im in sc.images]
-    m = api.Matcher()
-    m.set_params(api.default_params(box_hsize=args.box, box_vsize=args.box, n_best=args.n_best, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=2024))
+    pageable = [im.cpu().numpy() for im in sc.images]
+    pinned = []
+    for im in pageable:
+        a = api.pinned_empty(im.shape, np.float32)
+        a[...] = im
+        pinned.append(a)
+    out = {}
+    for leg, imgs in (("pinned", pinned), ("pageable", pageable)):
+        m = api.Matcher()
+        m.set_params(api.default_params(box_hsize=args.box, box_vsize=args.box, n_best=args.n_best, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=2024))
+        t0 = time.perf_counter()
+        m.set_views(imgs, sc.K, sc.R, sc.t)
+        t1 = time.perf_counter()
+        m.pm_init()
+        m.pm_iterate(args.iters)
+        m.compute_disp()
+        t2 = time.perf_counter()
+        res = m.get_result(("depth", "normal", "cost"), pinned=(leg == "pinned"))
+        t3 = time.perf_counter()
+        m.close()
+        del res
+        out[leg] = {"value": w * h / (t3 - t0) / 1e6, "unit": "Mpix/s", "set_views_h2d_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3,
+                    "get_result_d2h_ms": (t3 - t2) * 1e3}
+    return {"value": out["pinned"]["value"], "unit": "Mpix/s", "pinned": out["pinned"], "pageable": out["pageable"],
+            "note": "host buffers in (H2D + quad build), host buffers out (D2H); one view; value = page-locked caller buffers (tsar_host_alloc)"}
+
+
+def strict_mode_record(args, sc, local_rank):
+    """The same step in the oracle-exact arithmetic (TSAR_FLAG_STRICT_DIV): what the bit-exact parity tests run."""
+    from tsar_mvs_amd import api
+    m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024, device=local_rank, flags=api.FLAG_STRICT_DIV)
+    m.enable_kernel_timing(True)
+    steps = 2
+
+    def one():
+        m.pm_init()
+        m.pm_iterate(args.iters)
+        m.compute_disp()
+    one()
+    m.reset_kernel_timing()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    m.set_views(host_imgs, sc.K, sc.R, sc.t)
-    t1 = time.perf_counter()
-    m.pm_init()
-    m.pm_iterate(args.iters)
-    m.compute_disp()
-    t2 = time.perf_counter()
-    m.get_result(("depth", "normal", "cost"))
-    t3 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = m.kernel_timing()
     m.close()
-    return {"value": w * h / (t3 - t0) / 1e6, "unit": "Mpix/s", "set_views_h2d_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3,
-            "get_result_d2h_ms": (t3 - t2) * 1e3, "note": "pageable host buffers in, host buffers out; one view"}
+    rec = {"value": args.width * args.height * steps / dt / 1e6, "unit": "Mpix/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "note": "TSAR_FLAG_STRICT_DIV: IEEE divides and the oracle's operation order, bit-identical to the CPU oracle"}
+    if "pm_sweep" in timing and timing["pm_sweep"][0] > 0:
+        rec["pm_sweep_avg_launch_ms"] = timing["pm_sweep"][1] / timing["pm_sweep"][0]
+    return rec
 
 
 def main():
@@ -147,6 +186,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true", dest="no_host_boundary")
+    ap.add_argument("--no-strict-record", action="store_true", dest="no_strict_record")
+    ap.add_argument("--verify-gather", action="store_true", dest="verify_gather",
+                    help="after the timed steps, check that rank 0's gathered buffers hold every rank's own results (bit for bit)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -181,27 +223,48 @@ def main():
     sc = synth.make_scene(args.width, args.height, args.views, device=dev, seed=1234, cam_seed=42 + rank, step=args.cam_step)
     m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024 + rank, device=local_rank)
     w, h = args.width, args.height
-    out_depth = torch.empty((h, w), dtype=torch.float32, device=dev)
-    out_normal = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
-    out_cost = torch.empty((h, w), dtype=torch.float32, device=dev)
+    # Two sets of result buffers: the gather of step k (RCCL, asynchronous, on the collective's own stream) runs while the
+    # kernels of step k+1 fill the other set; a set is reused only after its gather has completed.
+    n_sets = 2 if dist is not None else 1
+    sets = [[torch.empty((h, w), dtype=torch.float32, device=dev), torch.empty((h, w, 3), dtype=torch.float32, device=dev),
+             torch.empty((h, w), dtype=torch.float32, device=dev)] for _ in range(n_sets)]
+    use_host_staging = dist is not None and backend != "nccl"
+    staged = [[t.cpu() for t in st] for st in sets] if use_host_staging else None
+    gathered = [alloc_gather_buffers(dist, staged[k] if use_host_staging else sets[k], dst=0) for k in range(n_sets)] if dist is not None else None
+    pending = [None] * n_sets
+    state = {"k": 0, "last": 0}
 
-    results = [out_depth, out_normal, out_cost]
-    staged = [t.cpu() for t in results] if (dist is not None and backend != "nccl") else None
-    gathered = alloc_gather_buffers(dist, staged if staged is not None else results, dst=0) if dist is not None else None
+    def wait_set(k):
+        if pending[k] is not None:
+            for wk in pending[k]:
+                wk.wait()
+            pending[k] = None
 
     def step():
+        k = state["k"] % n_sets
+        wait_set(k)                                   # the gather that last read this set
+        out_depth, out_normal, out_cost = sets[k]
         m.pm_init()
         m.pm_iterate(args.iters)
         m.compute_disp()
-        m.get_result_device(depth=out_depth, normal=out_normal, cost=out_cost)
+        m.get_result_device(depth=out_depth, normal=out_normal, cost=out_cost)     # complete on return (include/tsar.h)
         if dist is not None:
-            if staged is not None:
-                for s_, t in zip(staged, results):
+            src = sets[k]
+            if use_host_staging:
+                for s_, t in zip(staged[k], sets[k]):
                     s_.copy_(t)
-            gather_results(dist, staged if staged is not None else results, dst=0, out=gathered)
+                src = staged[k]
+            pending[k] = gather_results(dist, src, dst=0, out=gathered[k], async_op=True)
+        state["last"] = k
+        state["k"] += 1
+
+    def drain():
+        for k in range(n_sets):
+            wait_set(k)
 
     for _ in range(args.warmup):
         step()
+    drain()
     if not args.no_kernel_timing:
         m.enable_kernel_timing(True)
         m.reset_kernel_timing()
@@ -211,6 +274,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                           # every gather has landed on rank 0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -223,7 +287,19 @@ def main():
     timing = {} if args.no_kernel_timing else m.kernel_timing()
     # sanity on the product of the timed region (not part of the metric): converged depth vs the analytic scene
     gt = sc.gt_depth
+    out_depth = sets[state["last"]][0]
     frac_ok = float(((out_depth - gt).abs() / gt < 0.01).float().mean().item())
+
+    gather_check = None
+    if dist is not None and args.verify_gather:
+        def checksums(ts):
+            return [int(t.contiguous().view(torch.int32).to(torch.int64).sum().item()) for t in ts]
+        mine = checksums(sets[state["last"]])
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            got = [checksums([gathered[state["last"]][k][r] for k in range(3)]) for r in range(world)]
+            gather_check = {"verified": got == everyone, "ranks_differ": len({tuple(c) for c in everyone}) == world, "per_rank_depth_checksum": [c[0] for c in everyone]}
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -233,6 +309,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ETH3D-size view {w}x{h}, 1 ref + {args.views} src views, {args.iters} PatchMatch iters, box {args.box}, n_best {args.n_best}; one ref view per GPU",
+                       "mode": "fast",      # default arithmetic of the library and CLI; tolerance vs the oracle: tests/test_gpu_fast_mode.py; "strict" below = oracle-exact
                        "width": w, "height": h, "src_views": args.views, "iters": args.iters, "frac_depth_within_1pct_of_gt": round(frac_ok, 4)},
         }
         if "pm_sweep" in timing and timing["pm_sweep"][0] > 0:
@@ -248,6 +325,10 @@ def main():
             tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
             line["roofline"]["valu"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flops_per_launch": flops_per_launch}
             line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
+        if gather_check is not None:
+            line["gather_check"] = gather_check
+        if world == 1 and not args.no_strict_record:
+            line["strict"] = strict_mode_record(args, sc, local_rank)
         if world == 1 and not args.no_host_boundary:
             line["host_boundary"] = host_boundary(args, sc)
         if world == 1 and not args.no_cpu_baseline:

@@ -19,11 +19,13 @@
  *   gipuma_init_cu2            (gipuma.cu:678-729)       tsar_pm_init
  *   red/black prop+refine loop (gipuma.cu:1744-1754,     tsar_pm_iterate
  *     bodies :846-1138)
+ *   the same kernels with `final == true`                tsar_pm_iterate_final
+ *     (gipuma.cu:856,1063,559-562,669-672; lines->text)
  *   pmCostMultiview_cu on a given plane map              tsar_pm_cost_planes (test / diagnostics hook)
  *     (gipuma.cu:455-518)
  *   host fill of norm4/depth/c + firstcuda               tsar_load_planes
  *     (main.cpp:1479-1493, gipuma_get_disp gipuma.cu:731-755)
- *   weak.png → lines->scale (main.cpp:1499-1514)         tsar_set_reliable_mask
+ *   weak.png → lines->scale (main.cpp:1499-1514)         tsar_set_reliable_mask / tsar_get_reliable_mask
  *   gipuma_getlrdiff           (gipuma.cu:1160-1186)     tsar_lrdiff
  *   sliccuda → gipuma_getview  (gipuma.cu:1188-1213)     tsar_getview
  *   gipuma_WMF / gipuma_WMF_Final (gipuma.cu:1294-1698)  tsar_wmf
@@ -50,12 +52,19 @@
  *   - one tsar_ctx per device and per host thread; all work of a context is issued on one HIP
  *     stream (tsar_get_stream) and the call returns after that work is complete unless the
  *     function says it is asynchronous.
+ *   - TSAR_MEM_DEVICE inputs are read on the context's own (non-blocking) stream, which is not ordered against
+ *     any other stream: the work that produces them (a kernel on another stream, an RCCL collective, a copy)
+ *     must be COMPLETE before the call, e.g. by synchronising the producing stream or by making it wait
+ *     on an event the caller then synchronises.  TSAR_MEM_DEVICE outputs are complete when the call returns.
+ *   - host buffers from tsar_host_alloc are page-locked: copies to and from them run at PCIe rate without the
+ *     runtime's bounce buffers.  Any other host memory works too, slower.
  *   - images are row-major float32 gray, values as produced by an 8-bit decode (0..255); planes are
  *     row-major float32 [h][w] (or [h][w][3]/[h][w][4]).
  */
 #ifndef TSAR_H_
 #define TSAR_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -149,14 +158,19 @@ int tsar_set_params(tsar_ctx* ctx, const tsar_params* p);
  * camera is K[I|0] (cameraGeometryUtils.h:270-302).  Must follow tsar_set_params. */
 int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem,
                    const tsar_camera* cams);
-/* indices (1..n_views-1) of the source views used for matching, in pair.txt order.
- * Default after tsar_set_views: all source views. */
+/* indices (1..n_views-1) of the source views used for matching, in pair.txt order; at most 32 (the reference's
+ * costVector[32], gipuma.cu:467).  Default after tsar_set_views: the first min(n_views - 1, 32) source views.
+ * Changing the subset invalidates the stored costs' meaning: the next sweep re-scores neighbours it would otherwise skip. */
 int tsar_set_view_subset(tsar_ctx* ctx, int n, const int32_t* view_idx);
 
 /* ---- PatchMatch (the north-star path) --------------------------------------------------- */
 int tsar_pm_init(tsar_ctx* ctx);
 /* `iters` red/black iterations; each = black (prop+refine) then red (prop+refine). */
 int tsar_pm_iterate(tsar_ctx* ctx, int iters);
+/* The same loop with the kernels' `final` argument true (dormant in the reference: nothing passes true).
+ * text [h][w] = lines->text: pixels with text == -1 keep their plane and cost (gipuma.cu:856, :1063) and
+ * accepted hypotheses do not update ratio / best view (gipuma.cu:559-562, :669-672). */
+int tsar_pm_iterate_final(tsar_ctx* ctx, int iters, const float* text, int mem);
 /* Diagnostics: multi-view cost of caller-supplied planes.  planes = [h][w][4] (n_x,n_y,n_z,d) in
  * reference-camera coordinates; outputs [h][w]; beview/ratio may be NULL. */
 int tsar_pm_cost_planes(tsar_ctx* ctx, const float* planes, int mem, float* cost_out,
@@ -183,11 +197,12 @@ int tsar_get_result(tsar_ctx* ctx, float* depth, float* normal_world, float* cos
 
 /* ---- TSAR textureless refinement (reference gipuma.cu:1160-1698, main.cpp:1499-1783) ------ */
 int tsar_set_reliable_mask(tsar_ctx* ctx, const float* scale, int mem);          /* lines->scale */
+int tsar_get_reliable_mask(tsar_ctx* ctx, float* scale, int mem);                /* lines->scale as tsar_wmf leaves it */
 int tsar_lrdiff(tsar_ctx* ctx);
 int tsar_getview(tsar_ctx* ctx);
 int tsar_wmf(tsar_ctx* ctx, int iters, int final_pass);
 /* labels [h][w] = region id per pixel (lines->canny); region_text[n_regions] = -1 for textureless
- * regions (cannylines->text). */
+ * regions (cannylines->text).  Every label must lie in [0, n_regions): checked, TSAR_ERR_INVALID otherwise. */
 int tsar_set_regions(tsar_ctx* ctx, const int32_t* labels, int n_regions, const float* region_text,
                      const float* region_size, int mem);
 /* Weak-texture region detection of the reference view on the GPU (reference texture(), main.cpp:365-596):
@@ -227,6 +242,12 @@ int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, co
               const float* const* normal_world, const float* const* gray, int mem, const int32_t* src_off,
               const int32_t* src_idx, const tsar_fusion_params* params, float* points_out, int64_t cap,
               int64_t* n_points_out);
+
+/* ---- page-locked host buffers --------------------------------------------------------------- */
+/* NULL on failure.  Replaces the reference's cudaMallocManaged host-visible planes (managed.h:7-15) on the host side of the
+ * boundary: the caller's image / result buffers, allocated here, are DMA targets. */
+void* tsar_host_alloc(size_t bytes);
+void tsar_host_free(void* p);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream. */

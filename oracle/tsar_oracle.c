@@ -252,10 +252,9 @@ void orc_view_vector(const orc_state *s, int x, int y, float *v) { view_vector(&
 
 /* getHomography_cu gipuma.cu:207-224: H = K_to * ((R - t n^T / d) * K_ref^-1) */
 static inline void homography(const orc_camera *ref, const orc_camera *to, const float *n4, float *H) {
-    float inv_d = 1.0f / n4[3];
     float M[9], T[9];
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) M[r * 3 + c] = to->R[r * 3 + c] - (to->t[r] * n4[c]) * inv_d;
+    for (int r = 0; r < 3; r++)   /* outer_product4, then matdivide: every element divided by d (config.h:139-148) */
+        for (int c = 0; c < 3; c++) M[r * 3 + c] = to->R[r * 3 + c] - (to->t[r] * n4[c]) / n4[3];
     mat3mul(M, ref->Kinv, T);
     mat3mul(to->K, T, H);
 }
@@ -525,8 +524,11 @@ int orc_refine_steps(const orc_state *s) {
 
 /* one launch = propagation then refinement of every pixel of one colour.
  * colour 0 = "black": (x + y) even  (gipuma.cu:1099-1103: even x -> even y, odd x -> odd y),
- * colour 1 = "red".  do_prop / do_refine allow testing the halves separately. */
-void orc_pm_sweep(orc_state *s, int colour, int do_prop, int do_refine) {
+ * colour 1 = "red".  do_prop / do_refine allow testing the halves separately.
+ * final_text != NULL is the kernels' `final == true` mode: pixels whose lines->text is -1 are left
+ * untouched (gipuma.cu:856, :1063) and accepted hypotheses do not write ratio / beview
+ * (gipuma.cu:559-562, :669-672). */
+static void pm_sweep_impl(orc_state *s, int colour, int do_prop, int do_refine, const float *final_text) {
     const size_t np = (size_t)s->w * s->h;
     float *c_snap = (float *)malloc(np * sizeof(float));
     float *n_snap = (float *)malloc(np * 4 * sizeof(float));
@@ -538,6 +540,7 @@ void orc_pm_sweep(orc_state *s, int colour, int do_prop, int do_refine) {
         for (int x = 0; x < s->w; x++) {
             if (((x + y) & 1) != colour) continue;
             size_t p = (size_t)y * s->w + x;
+            if (final_text && final_text[p] == -1.0f) continue;
             pix_t px;
             px.cost = c_snap[p]; memcpy(px.n4, n_snap + 4 * p, 16);
             px.depth = depth_from_plane(&s->cam[0], px.n4, x, y);
@@ -545,16 +548,24 @@ void orc_pm_sweep(orc_state *s, int colour, int do_prop, int do_refine) {
             if (do_prop) propagate_pixel(s, c_snap, n_snap, x, y, &px);
             if (do_refine) refine_pixel(s, x, y, stream, &px);
             s->c[p] = px.cost; memcpy(s->norm4 + 4 * p, px.n4, 16);
-            if (px.wrote) { s->ratio[p] = px.ratio; s->beview[p] = px.beview; }
+            if (px.wrote && !final_text) { s->ratio[p] = px.ratio; s->beview[p] = px.beview; }
         }
     free(c_snap); free(n_snap);
     s->launch++;
 }
+void orc_pm_sweep(orc_state *s, int colour, int do_prop, int do_refine) { pm_sweep_impl(s, colour, do_prop, do_refine, NULL); }
 /* host loop of gipuma_first gipuma.cu:1744-1754 */
 void orc_pm_iterate(orc_state *s, int iters) {
     for (int it = 0; it < iters; it++) {
-        orc_pm_sweep(s, 0, 1, 1);
-        orc_pm_sweep(s, 1, 1, 1);
+        pm_sweep_impl(s, 0, 1, 1, NULL);
+        pm_sweep_impl(s, 1, 1, 1, NULL);
+    }
+}
+/* the same loop with the kernels' `final` argument true; text [h][w] = lines->text */
+void orc_pm_iterate_final(orc_state *s, int iters, const float *text) {
+    for (int it = 0; it < iters; it++) {
+        pm_sweep_impl(s, 0, 1, 1, text);
+        pm_sweep_impl(s, 1, 1, 1, text);
     }
 }
 

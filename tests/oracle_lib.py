@@ -62,7 +62,7 @@ def lib():
         L.orc_set_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
         L.orc_derive_cameras.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.orc_rng4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
-        for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_iterate", "orc_pm_cost_planes",
+        for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_iterate", "orc_pm_iterate_final", "orc_pm_cost_planes",
                   "orc_select_candidates", "orc_homography", "orc_view_vector", "orc_load_planes", "orc_compute_disp",
                   "orc_depth_to_plane", "orc_compute_disp_final", "orc_lrdiff", "orc_getview", "orc_fake_depth",
                   "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch", "orc_wmf_detect", "orc_wmf_fill",
@@ -220,6 +220,11 @@ class Oracle:
         self.L.orc_select_candidates(self.s, _p(c), C.c_int(x), C.c_int(y), _p(out))
         return out
 
+    def set_subset(self, subset):
+        sub = np.asarray(subset, dtype=np.int32)
+        self.L.orc_set_subset(self.s, len(sub), _p(sub))
+        self.n_sel = len(sub)
+
     def pm_init(self):
         self.L.orc_pm_init(self.s)
 
@@ -228,6 +233,11 @@ class Oracle:
 
     def pm_iterate(self, iters):
         self.L.orc_pm_iterate(self.s, C.c_int(iters))
+
+    def pm_iterate_final(self, iters, text):
+        """the kernels' `final == true` mode (reference gipuma.cu:856,1063,559-562,669-672); text [h][w] = lines->text"""
+        tx = np.ascontiguousarray(text, np.float32)
+        self.L.orc_pm_iterate_final(self.s, C.c_int(iters), _p(tx))
 
     def set_launch(self, n):
         self.L.orc_set_launch(self.s, C.c_int(n))

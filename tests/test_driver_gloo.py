@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tsar_mvs_amd.driver import gather_results, owner_of_view, shard_views
+from tsar_mvs_amd.driver import alloc_gather_buffers, gather_results, owner_of_view, shard_views
 
 
 def test_shard_views_partitions_all_views():
@@ -67,3 +67,51 @@ def test_gather_results_world_size_2():
         assert p.exitcode == 0
     assert all(r[0] for r in res)
     assert sorted(sum((r[1] for r in res), [])) == [0, 1, 2, 3, 4]
+
+
+def _worker_async(rank, world, port, q):
+    """bench.py's double-buffered loop: the gather of step k is in flight while step k+1 fills the other buffer set"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sets = [[torch.zeros((6, 8)), torch.zeros((6, 8, 3))] for _ in range(2)]
+    recv = [alloc_gather_buffers(dist, st, dst=0) for st in sets]
+    pending = [None, None]
+    seen = []
+    ok = True
+    for step in range(5):
+        k = step % 2
+        if pending[k] is not None:
+            for wk in pending[k]:
+                wk.wait()
+            if rank == 0:                                  # the set now holds step - 2 of every rank
+                seen.append([float(recv[k][0][r][0, 0]) for r in range(world)])
+        sets[k][0].fill_(100.0 * step + rank)              # "compute" step into set k
+        sets[k][1].fill_(-(100.0 * step + rank))
+        pending[k] = gather_results(dist, sets[k], dst=0, out=recv[k], async_op=True)
+    for k in ((5 % 2), (6 % 2)):                            # drain in issue order: step 3 then step 4
+        for wk in pending[k]:
+            wk.wait()
+        if rank == 0:
+            seen.append([float(recv[k][0][r][0, 0]) for r in range(world)])
+    if rank == 0:
+        ok = seen == [[100.0 * st + r for r in range(world)] for st in range(5)]
+        ok &= all(float(recv[0][1][r][0, 0, 0]) == -(400.0 + r) for r in range(world))
+    if rank != 0:
+        ok &= recv[0] is None
+    q.put((bool(ok), seen))
+    dist.destroy_process_group()
+
+
+def test_async_double_buffered_gather_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] for r in res), res

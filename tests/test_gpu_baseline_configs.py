@@ -131,6 +131,8 @@ def test_cfg2_full_size_properties():
 def test_lds_patch_sweep_variant_bit_exact(monkeypatch):
     """the opt-in LDS-patch form of the sweep (pm_sweep_lds.hip, TSAR_LDS_SWEEP=1): slower than the default kernel
      but kept as a measured alternative — it must produce the oracle's bits too"""
+    if b"+experiments" not in api.load_library().tsar_version():
+        pytest.skip("the LDS-patch sweep is an experiment: built only with `make TSAR_EXPERIMENTS=1` (tsar-mvs_amd/csrc/Makefile)")
     monkeypatch.setenv("TSAR_LDS_SWEEP", "1")
     sc = synth.make_scene(192, 128, 4, seed=11)
     orc = _oracle(sc, seed=5)

@@ -1,0 +1,60 @@
+"""Multi-rank control flow of bench.py on ONE GPU (the 8-GPU legs are the driver's to run).
+
+bench.py --gpus 2 is launched exactly as the driver launches it (python -m torch.distributed.run, one rank per process,
+fresh processes), with TSAR_BENCH_BACKEND=gloo so that both ranks may share the single device of the test box: each
+rank matches its own reference view, the results are gathered to rank 0 through the double-buffered asynchronous
+gather, and --verify-gather checks on rank 0 that every gathered buffer equals the sending rank's own output bit for
+bit.  What this cannot show is RCCL itself moving the bytes over xGMI — that row stays "unmeasured on hardware".
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_bench(world, extra, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update({"TSAR_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_gather_is_bit_exact():
+    line = _run_bench(2, ["--steps", "3", "--warmup", "1", "--width", "640", "--height", "480", "--views", "4", "--iters", "2",
+                          "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing"])
+    assert line["gather_check"]["verified"] is True, line["gather_check"]
+    assert line["gather_check"]["ranks_differ"] is True, line["gather_check"]     # each rank matched its own view
+    assert line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["mode"] == "fast"
+    # whole-job value = the pixels of both ranks over the max-over-ranks time
+    assert abs(line["value"] - 2 * 640 * 480 * 3 / (line["ms_per_step"] * 3e-3) / 1e6) < 1e-6 * line["value"]
+    assert line["config"]["frac_depth_within_1pct_of_gt"] > 0.5
+
+
+def test_bench_three_ranks_odd_step_count():
+    """an odd number of steps ends on the other buffer set; three ranks on the one device"""
+    line = _run_bench(3, ["--steps", "2", "--warmup", "0", "--width", "320", "--height", "240", "--views", "3", "--iters", "1",
+                          "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing"])
+    assert line["gather_check"]["verified"] is True and line["gather_check"]["ranks_differ"] is True
+    assert len(line["gather_check"]["per_rank_depth_checksum"]) == 3

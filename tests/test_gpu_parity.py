@@ -281,7 +281,84 @@ def test_lrdiff_confidence(small_scene):
     m.close()
 
 
-def test_error_codes():
+def test_compute_disp_final_bit_exact(small_scene):
+    """gipuma_compute_disp_final (reference gipuma.cu:757-808) on the case that drives every branch: text 0 / 1 / -1,
+    disparity difference above and below the threshold of 6, clamps at depthMin and depthMax, MAXCOST export"""
+    from test_oracle_known_answers import _merge_case
+    sc = small_scene
+    orc = _oracle(sc)
+    rs, text, exp_d, took = _merge_case(sc, orc)
+    m = api.matcher_from_scene(sc)
+    m.set_plane(orc.norm4.copy(), orc.c.copy())
+    ref = orc.compute_disp_final(rs, text)
+    m.compute_disp_final(rs, text)
+    res = m.get_result(("depth", "normal", "cost"))
+    assert np.array_equal(res["depth"], ref[..., 3])
+    assert np.array_equal(res["normal"].view(np.uint32), ref[..., :3].view(np.uint32))
+    planes, _, _, _ = m.get_plane()
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))       # merged / clamped camera-frame planes
+    assert took.any() and (~took).any() and (res["depth"][0] == 0).all()
+    # a second case on a PatchMatch state: random text, upsampled planes = the state shifted by one pixel
+    orc2 = _oracle(sc, seed=14)
+    orc2.pm_init(); orc2.pm_iterate(1)
+    rng = np.random.default_rng(3)
+    text2 = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(sc.h, sc.w))
+    rs2 = np.roll(orc2.norm4, 1, axis=1).copy()
+    m.set_plane(orc2.norm4.copy(), orc2.c.copy())
+    ref2 = orc2.compute_disp_final(rs2, text2)
+    m.compute_disp_final(rs2, text2)
+    res2 = m.get_result(("depth", "normal"))
+    assert np.array_equal(res2["depth"], ref2[..., 3])
+    assert np.array_equal(res2["normal"].view(np.uint32), ref2[..., :3].view(np.uint32))
+    m.close()
+
+
+def test_final_mode_iterations_bit_exact(small_scene):
+    """the kernels' `final == true` mode (reference gipuma.cu:856, :1063, :559-562, :669-672), strict arithmetic"""
+    sc = small_scene
+    rng = np.random.default_rng(8)
+    text = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), size=(sc.h, sc.w), p=[0.3, 0.4, 0.3])
+    text[:, : sc.w // 4] = -1.0
+    orc = _oracle(sc, seed=21)
+    orc.pm_init()
+    orc.pm_iterate(1)
+    m = api.matcher_from_scene(sc, seed=21, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(1)
+    orc.pm_iterate_final(2, text)
+    m.pm_iterate_final(2, text)
+    planes, cost, bv, rt = m.get_plane()
+    assert np.array_equal(cost, orc.c)
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(bv, orc.beview) and np.array_equal(rt.view(np.uint32), orc.ratio.view(np.uint32))
+    # ... and a normal iteration afterwards continues from it bit for bit
+    orc.pm_iterate(1)
+    m.pm_iterate(1)
+    planes, cost, _, _ = m.get_plane()
+    assert np.array_equal(cost, orc.c) and np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    m.close()
+
+
+def test_view_subset_change_mid_run_bit_exact(mid_scene):
+    """changing the scored views after the state exists: the stored costs no longer belong to the subset, so the sweep must
+    re-score a neighbour that carries the pixel's own plane like the reference does (gipuma.cu:540-556), not skip it"""
+    sc = mid_scene
+    orc = _oracle(sc, seed=4, subset=[1, 2])
+    orc.pm_init(); orc.pm_iterate(1)
+    m = api.matcher_from_scene(sc, seed=4, flags=api.FLAG_STRICT_DIV, subset=[1, 2])
+    m.pm_init(); m.pm_iterate(1)
+    orc.set_subset([3, 4, 1])
+    m.set_view_subset([3, 4, 1])
+    orc.pm_iterate(1)
+    m.pm_iterate(1)
+    planes, cost, bv, _ = m.get_plane()
+    assert np.array_equal(cost, orc.c)
+    assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(bv, orc.beview)
+    m.close()
+
+
+def test_error_codes(small_scene):
     m = api.Matcher()
     with pytest.raises(api.TsarError) as e:
         m.pm_init()
@@ -289,6 +366,39 @@ def test_error_codes():
     with pytest.raises(api.TsarError) as e:
         m.set_params(api.default_params(depth_min=5.0, depth_max=1.0))
     assert e.value.code == api.TSAR_ERR_INVALID
+    # limits that used to fail late or silently: more best views than the 32-entry cost vector, a box whose weight table
+    # cannot fit the LDS of a CU
+    for bad in (dict(n_best=33), dict(box_hsize=25, box_vsize=25), dict(box_hsize=63, box_vsize=11)):
+        with pytest.raises(api.TsarError) as e:
+            m.set_params(api.default_params(**bad))
+        assert e.value.code == api.TSAR_ERR_INVALID, bad
+    m.set_params(api.default_params(box_hsize=23, box_vsize=23))      # the largest square box is accepted
+    m.close()
+    sc = small_scene
+    m = api.matcher_from_scene(sc)
+    with pytest.raises(api.TsarError) as e:
+        m.set_view_subset(list(range(1, 3)) * 17)                      # 34 entries
+    assert e.value.code == api.TSAR_ERR_INVALID
+    # region labels index device tables: out-of-range labels are refused, host and device buffers alike, and leave the
+    # context usable
+    import torch
+    labels = np.zeros((sc.h, sc.w), np.int32)
+    text = np.array([1.0, -1.0], np.float32)
+    for bad_value in (2, -1, 1 << 20):
+        lb = labels.copy()
+        lb[sc.h // 2, sc.w // 2] = bad_value
+        with pytest.raises(api.TsarError) as e:
+            m.set_regions(lb, text)
+        assert e.value.code == api.TSAR_ERR_INVALID, bad_value
+        with pytest.raises(api.TsarError) as e:
+            m.set_regions(torch.from_numpy(lb).cuda(), text)
+        assert e.value.code == api.TSAR_ERR_INVALID, bad_value
+    labels[:, sc.w // 2:] = 1
+    m.set_regions(torch.from_numpy(labels).cuda(), text)
+    m.set_region_planes(np.array([[0, 0, 0, 0], [0, 0, -1, 5.0]], np.float32))
+    m.pm_init()
+    m.fill_textureless()
+    assert (m.get_result(("cost",), pinned=True)["cost"][:, sc.w // 2:] == 0).all()
     m.close()
 
 
@@ -321,9 +431,10 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     for it in range(4):
         orc.wmf_detect(it)
     m.wmf(4, False)
-    import ctypes as C
-    got_scale = np.empty((h, w), np.float32)
-    # scale is read back through the fill below; check detect through its effect on a final pass
+    # the reliability map the four detection passes leave in lines->scale
+    got_scale = m.get_reliable_mask()
+    assert np.array_equal(got_scale, orc.scale)
+    assert 0.02 < (got_scale != scale).mean() < 0.98      # the passes did change it
     for it in range(3):
         orc.wmf_fill(it)
     m.wmf(3, True)

@@ -280,6 +280,87 @@ def test_load_planes_compute_disp_round_trip(small_scene):
     assert o.compute_disp()[0, 0, 3] == 0.0                 # MAXCOST pixels export depth 0 (gipuma.cu:838-841)
 
 
+def _merge_case(sc, o):
+    """state + inputs that drive every branch of gipuma_compute_disp_final (reference gipuma.cu:757-808): fronto-parallel
+    planes facing the camera at per-column-band depths, so that the expected output is known in closed form.
+    Returns (resize4, text, expected depth, expected 'took resize' mask)."""
+    h, w = sc.h, sc.w
+    c0 = o.camera(0)
+    f = float(c0.f)
+    dmin, dmax = float(c0.depthMin), float(c0.depthMax)
+    n = np.array([0.0, 0.0, -1.0], np.float32)       # camera looks along +z: n . view < 0
+    mid = 0.5 * (dmin + dmax)
+    # depth whose disparity differs from mid's by more / less than the 6-unit threshold of :778
+    near6 = f / (f / mid + 8.0)
+    close = f / (f / mid + 3.0)
+    bands = [  # (depth_now, depth_resize, text, expected depth, resize taken)
+        (mid, near6, 0.0, mid, False),          # text 0: never merged
+        (mid, near6, 1.0, near6, True),         # text 1 and |disp_now - disp_org| = 8 > 6: take the upsampled plane
+        (mid, close, 1.0, mid, False),          # text 1, difference 3 <= 6: keep
+        (mid, near6, -1.0, near6, True),        # text -1: always take the upsampled plane
+        (dmax * 1.5, mid, 0.0, dmax, False),    # beyond depthMax: plane offset re-derived at depthMax (:784-788)
+        (dmin * 0.5, mid, 0.0, dmin, False),    # before depthMin (:789-793)
+        (mid, dmax * 2.0, -1.0, dmax, True),    # merged AND clamped
+    ]
+    bw = w // len(bands)
+    now = np.zeros((h, w, 4), np.float32)
+    rs = np.zeros((h, w, 4), np.float32)
+    text = np.zeros((h, w), np.float32)
+    exp_d = np.zeros((h, w), np.float64)
+    took = np.zeros((h, w), bool)
+    for y in range(h):
+        for x in range(w):
+            d_now, d_rs, tx, d_exp, tk = bands[min(x // bw, len(bands) - 1)]
+            now[y, x, :3] = n; now[y, x, 3] = o.getD(n, x, y, d_now)
+            rs[y, x, :3] = n; rs[y, x, 3] = o.getD(n, x, y, d_rs)
+            text[y, x] = tx; exp_d[y, x] = d_exp; took[y, x] = tk
+    o.norm4[:] = now
+    o.c[:] = 0.5
+    o.c[0, :] = 2.0                                   # MAXCOST row: exported depth 0 (:802-805)
+    return rs, text, exp_d, took
+
+
+def test_compute_disp_final_known_answers(small_scene):
+    """gipuma_compute_disp_final gipuma.cu:757-808: hi-res / upsampled plane merge by lines->text and the 6-disparity
+    threshold, clamp of the merged plane into [depthMin, depthMax], world normal + depth (0 at MAXCOST) export"""
+    sc = small_scene
+    o = _orc(sc)
+    rs, text, exp_d, took = _merge_case(sc, o)
+    out = o.compute_disp_final(rs, text)
+    d = out[..., 3]
+    assert (d[0] == 0.0).all()
+    assert np.allclose(d[1:], exp_d[1:], rtol=3e-5)
+    assert np.allclose(o.depth, exp_d, rtol=3e-5)                       # lines->depth holds the merged depth (:797)
+    # merged pixels carry the upsampled plane's bits unless the clamp re-derived the offset
+    unclamped = took & (np.abs(exp_d - float(o.camera(0).depthMax)) > 1e-6)
+    assert np.array_equal(o.norm4[unclamped], rs[unclamped])
+    # normal export: R_orig^-1 n
+    n_world = (np.asarray(o.camera(0).RorigInv, np.float64).reshape(3, 3) @ np.array([0, 0, -1.0]))
+    assert np.allclose(out[..., :3], n_world, atol=2e-6)
+
+
+def test_final_mode_sweep_skips_text_minus_one_and_side_writes(small_scene):
+    """the kernels' `final == true` mode (gipuma.cu:856, :1063: return at text == -1; :559-562, :669-672: no ratio /
+    beview writes); everywhere else it is the ordinary iteration"""
+    sc = small_scene
+    a, b = _orc(sc, seed=31), _orc(sc, seed=31)
+    a.pm_init(); b.pm_init()
+    text = np.zeros((sc.h, sc.w), np.float32)
+    text[:, : sc.w // 3] = -1.0
+    text[:, 2 * sc.w // 3:] = 1.0
+    keep_c, keep_n = b.c.copy(), b.norm4.copy()
+    b.ratio[:] = 7.0; b.beview[:] = 9
+    a.pm_iterate(1)
+    b.pm_iterate_final(1, text)
+    frozen = text == -1.0
+    assert np.array_equal(b.c[frozen], keep_c[frozen]) and np.array_equal(b.norm4[frozen], keep_n[frozen])
+    assert (b.ratio == 7.0).all() and (b.beview == 9).all()
+    assert (b.c[~frozen] <= keep_c[~frozen]).all() and (b.c[~frozen] < keep_c[~frozen]).mean() > 0.5
+    # far from the frozen band (propagation reaches 23 px) both modes did exactly the same work
+    far = np.zeros_like(frozen); far[:, sc.w // 3 + 48:] = True
+    assert np.array_equal(a.c[far], b.c[far]) and np.array_equal(a.norm4[far], b.norm4[far])
+
+
 def test_textureless_fill(small_scene):
     sc = small_scene
     h, w = sc.h, sc.w

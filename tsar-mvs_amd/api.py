@@ -59,12 +59,12 @@ class KernelTiming(C.Structure):
 ABI_SYMBOLS = [
     "tsar_create", "tsar_destroy", "tsar_last_error", "tsar_version", "tsar_get_stream", "tsar_synchronize",
     "tsar_default_params", "tsar_set_params", "tsar_set_views", "tsar_set_view_subset",
-    "tsar_pm_init", "tsar_pm_iterate", "tsar_pm_sweep", "tsar_set_sweep_counter", "tsar_pm_cost_planes", "tsar_set_plane", "tsar_get_plane",
+    "tsar_pm_init", "tsar_pm_iterate", "tsar_pm_iterate_final", "tsar_pm_sweep", "tsar_set_sweep_counter", "tsar_pm_cost_planes", "tsar_set_plane", "tsar_get_plane",
     "tsar_load_planes", "tsar_compute_disp", "tsar_compute_disp_final", "tsar_depth_to_plane", "tsar_get_result",
-    "tsar_set_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
+    "tsar_set_reliable_mask", "tsar_get_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse",
-    "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
+    "tsar_host_alloc", "tsar_host_free", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
 ]
 
 _lib = None
@@ -93,6 +93,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_set_view_subset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.tsar_pm_init.argtypes = [C.c_void_p]
     L.tsar_pm_iterate.argtypes = [C.c_void_p, C.c_int]
+    L.tsar_pm_iterate_final.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.tsar_pm_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.tsar_set_sweep_counter.argtypes = [C.c_void_p, C.c_int]
     L.tsar_pm_cost_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -104,6 +105,11 @@ def load_library(path: str = LIB_PATH):
     L.tsar_depth_to_plane.argtypes = [C.c_void_p]
     L.tsar_get_result.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tsar_set_reliable_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_get_reliable_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_host_alloc.restype = C.c_void_p
+    L.tsar_host_alloc.argtypes = [C.c_size_t]
+    L.tsar_host_free.restype = None
+    L.tsar_host_free.argtypes = [C.c_void_p]
     L.tsar_lrdiff.argtypes = [C.c_void_p]
     L.tsar_getview.argtypes = [C.c_void_p]
     L.tsar_wmf.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -145,6 +151,11 @@ def _ptr(a):
         return None, MEM_HOST
     if _is_torch(a):
         assert a.is_contiguous(), "tensor must be contiguous"
+        if a.is_cuda:
+            # include/tsar.h: device buffers must be complete before the call — the context's stream is not ordered
+            # against torch's.  Whatever produced (or still reads) this tensor ran on torch's current stream.
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
         return C.c_void_p(a.data_ptr()), (MEM_DEVICE if a.is_cuda else MEM_HOST)
     assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
     return a.ctypes.data_as(C.c_void_p), MEM_HOST
@@ -222,6 +233,12 @@ class Matcher:
     def pm_iterate(self, iters: int):
         self._chk(self.L.tsar_pm_iterate(self._ctx, iters))
 
+    def pm_iterate_final(self, iters: int, text):
+        """the kernels' `final == true` mode; text [h, w] = lines->text (-1: pixel is left untouched)"""
+        t = text if _is_torch(text) else np.ascontiguousarray(text, np.float32)
+        p, kind = _ptr(t)
+        self._chk(self.L.tsar_pm_iterate_final(self._ctx, iters, p, kind))
+
     def pm_sweep(self, colour: int, do_prop: bool = True, do_refine: bool = True):
         self._chk(self.L.tsar_pm_sweep(self._ctx, colour, int(do_prop), int(do_refine)))
 
@@ -270,12 +287,14 @@ class Matcher:
     def depth_to_plane(self):
         self._chk(self.L.tsar_depth_to_plane(self._ctx))
 
-    def get_result(self, want=("depth", "normal", "cost", "confid")):
+    def get_result(self, want=("depth", "normal", "cost", "confid"), pinned=False):
+        """pinned=True: the result arrays are page-locked (tsar_host_alloc), so the D2H copies run at PCIe rate"""
         out = {}
-        depth = np.empty((self.h, self.w), np.float32) if "depth" in want else None
-        normal = np.empty((self.h, self.w, 3), np.float32) if "normal" in want else None
-        cost = np.empty((self.h, self.w), np.float32) if "cost" in want else None
-        confid = np.empty((self.h, self.w), np.float32) if "confid" in want else None
+        empty = pinned_empty if pinned else np.empty
+        depth = empty((self.h, self.w), np.float32) if "depth" in want else None
+        normal = empty((self.h, self.w, 3), np.float32) if "normal" in want else None
+        cost = empty((self.h, self.w), np.float32) if "cost" in want else None
+        confid = empty((self.h, self.w), np.float32) if "confid" in want else None
         self._chk(self.L.tsar_get_result(self._ctx, _ptr(depth)[0], _ptr(normal)[0], _ptr(cost)[0], _ptr(confid)[0], MEM_HOST))
         for k, v in (("depth", depth), ("normal", normal), ("cost", cost), ("confid", confid)):
             if v is not None:
@@ -291,6 +310,11 @@ class Matcher:
         s = np.ascontiguousarray(scale, np.float32)
         self._chk(self.L.tsar_set_reliable_mask(self._ctx, _ptr(s)[0], MEM_HOST))
 
+    def get_reliable_mask(self):
+        s = np.empty((self.h, self.w), np.float32)
+        self._chk(self.L.tsar_get_reliable_mask(self._ctx, _ptr(s)[0], MEM_HOST))
+        return s
+
     def lrdiff(self):
         self._chk(self.L.tsar_lrdiff(self._ctx))
 
@@ -301,10 +325,18 @@ class Matcher:
         self._chk(self.L.tsar_wmf(self._ctx, iters, int(final_pass)))
 
     def set_regions(self, labels, region_text, region_size=None):
-        lb = np.ascontiguousarray(labels, np.int32)
         tx = np.ascontiguousarray(region_text, np.float32)
         sz = np.ascontiguousarray(region_size, np.float32) if region_size is not None else None
-        self._chk(self.L.tsar_set_regions(self._ctx, _ptr(lb)[0], len(tx), _ptr(tx)[0], _ptr(sz)[0], MEM_HOST))
+        if _is_torch(labels) and labels.is_cuda:
+            # labels on the device; the (small) region tables travel to the device the same way
+            import torch
+            assert labels.dtype == torch.int32
+            txd = torch.from_numpy(tx).to(labels.device)
+            szd = torch.from_numpy(sz).to(labels.device) if sz is not None else None
+            self._chk(self.L.tsar_set_regions(self._ctx, _ptr(labels)[0], len(tx), _ptr(txd)[0], _ptr(szd)[0], MEM_DEVICE))
+        else:
+            lb = np.ascontiguousarray(labels, np.int32)
+            self._chk(self.L.tsar_set_regions(self._ctx, _ptr(lb)[0], len(tx), _ptr(tx)[0], _ptr(sz)[0], MEM_HOST))
         self.n_regions = len(tx)
 
     def detect_weak_texture(self, cap: int = 1 << 16):
@@ -422,3 +454,26 @@ def fuse(depths, normals, grays, K, R, t, pairs, params: FusionParams | None = N
     if rc != TSAR_OK:
         raise TsarError(rc, "tsar_fuse failed")
     return out[: min(cnt.value, cap)].copy()
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array over page-locked host memory from tsar_host_alloc (freed when the array is collected)"""
+    L = load_library()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = L.tsar_host_alloc(n)
+    if not p:
+        raise MemoryError(f"tsar_host_alloc({n}) failed")
+    buf = (C.c_char * n).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+
+    class _Owner:
+        def __del__(self, p=p, L=L):
+            L.tsar_host_free(p)
+    _owners[id(buf)] = (_Owner(), buf)
+    import weakref
+    weakref.finalize(arr, _owners.pop, id(buf), None)
+    return arr
+
+
+_owners = {}

@@ -214,3 +214,38 @@ int launch_fake_depth(tsar_ctx* ctx) {
 int launch_split_out4(tsar_ctx* ctx, float* depth, float* normal3) {
     EW_LAUNCH(ctx, "split_out4", split_out4_kernel, ctx->out4, depth, normal3, ctx->w * ctx->h);
 }
+
+// ---- label range (tsar_set_regions validation) ---------------------------------------------------
+__global__ __launch_bounds__(EW_BLOCK) void label_range_kernel(const int32_t* __restrict__ labels, size_t n, int32_t* __restrict__ lohi) {
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (size_t k = (size_t)blockIdx.x * EW_BLOCK + threadIdx.x; k < n; k += (size_t)gridDim.x * EW_BLOCK) {
+        const int32_t v = labels[k];
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&lohi[0], lo); atomicMax(&lohi[1], hi); }
+}
+int launch_label_range(tsar_ctx* ctx, const int32_t* labels, size_t n, int32_t* lo, int32_t* hi) {
+    int32_t* d = nullptr;
+    if (hipMalloc((void**)&d, 2 * sizeof(int32_t)) != hipSuccess) { ctx->err = "hipMalloc failed"; return TSAR_ERR_NOMEM; }
+    const int32_t init[2] = {INT32_MAX, INT32_MIN};
+    int32_t out[2] = {0, 0};
+    const size_t blocks = (n + EW_BLOCK - 1) / EW_BLOCK;
+    hipError_t e = hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(label_range_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(EW_BLOCK), 0, ctx->stream, labels, n, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof out, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) { ctx->err = std::string("label range check: ") + hipGetErrorString(e); return TSAR_ERR_HIP; }
+    *lo = out[0];
+    *hi = out[1];
+    return TSAR_OK;
+}

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
                                                             int32_t* __restrict__ beview_out, uint32_t stream_id, int do_prop,
-                                                            int do_refine, int tiles_x, int n_tiles, int cost_consistent, int strip_w) {
+                                                            int do_refine, int tiles_x, int n_tiles, int cost_consistent, int strip_w,
+                                                            const float* __restrict__ final_text) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename TileOf<QUAD>::type TileT;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
@@ -161,6 +162,9 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
 
     float cost_now = c_same[p];
     float4 n_now = n_same[p];
+    // the kernels' `final == true` mode (gipuma.cu:856, :1063): pixels whose lines->text is -1 keep their state
+    // (copied across the ping-pong), and no accepted hypothesis writes ratio / beview (:559-562, :669-672)
+    if (final_text && final_text[p] == -1.0f) { c_out[p] = cost_now; n_out[p] = n_now; return; }
     const PixelRef pr = hoist_reference<HR, TileT>(tile, tw, own, wts, hr, vr);
     bool wrote = false;
     float ratio_w = 0.f;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
     }
     c_out[p] = cost_now;
     n_out[p] = n_now;
-    if (wrote) { ratio_out[p] = ratio_w; beview_out[p] = beview_w; }
+    if (wrote && !final_text) { ratio_out[p] = ratio_w; beview_out[p] = beview_w; }
 }
 
 
@@ -250,7 +254,7 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
         ScopedKernelTimer tm(ctx, "pm_sweep");
         hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
                            other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles,
-                           ctx->cost_consistent ? 1 : 0, strip_width(ctx->strip_w, tiles_x));
+                           ctx->cost_consistent ? 1 : 0, strip_width(ctx->strip_w, tiles_x), ctx->final_text);
     }
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;
@@ -268,11 +272,13 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     }
     if (quad && NB == 2 && HR == 5) {   // the production configuration: code-generation variants (TSAR_VARIANT)
         switch (ctx->variant) {
+#ifdef TSAR_EXPERIMENTS   // diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1); the product carries 50 and 58 only
             case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
             case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
             case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
             case 18: return launch_sweep_t<2, 5, false, true, 18>(ctx, colour, a, b, c, sid, dp, dr);
             case 26: return launch_sweep_t<2, 5, false, true, 26>(ctx, colour, a, b, c, sid, dp, dr);
+#endif
             case 50: return launch_sweep_t<2, 5, false, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
             case 58: return launch_sweep_t<2, 5, false, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
             default: break;
@@ -284,11 +290,13 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                     int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
-    if (ctx->lds_sweep) {   // opt-in LDS-patch form for 8-bit imagery, box 11, n_best <= 2, <= 10 views (pm_sweep_lds.hip)
+#ifdef TSAR_EXPERIMENTS
+    if (ctx->lds_sweep && !ctx->final_text) {   // opt-in LDS-patch form for 8-bit imagery, box 11, n_best <= 2, <= 10 views (pm_sweep_lds.hip)
         int launched = 0;
         const int rc = launch_pm_sweep_lds(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine, &launched);
         if (rc != TSAR_OK || launched) return rc;
     }
+#endif
     const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;
     const bool r5 = hs.hrad == 5 && hs.vrad == 5;
     if (need <= 2) return r5 ? launch_sweep_nh<2, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)

@@ -18,7 +18,8 @@ ScopedKernelTimer::ScopedKernelTimer(tsar_ctx* c, const char* name) : ctx(c) {
         ctx->timers.back().name = name;
         t = &ctx->timers.back();
     }
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { t = nullptr; return; }
+    if (hipEventCreate(&e0) != hipSuccess) { t = nullptr; return; }
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); t = nullptr; return; }
     hipEventRecord(e0, ctx->stream);
 }
 ScopedKernelTimer::~ScopedKernelTimer() {
@@ -67,6 +68,24 @@ static hipMemcpyKind out_kind(int mem) { return mem == TSAR_MEM_DEVICE ? hipMemc
 #define NEED_VIEWS(ctx) if (!(ctx)->have_views) return fail(ctx, TSAR_ERR_STATE, "tsar_set_views has not been called")
 #define NEED_STATE(ctx) if (!(ctx)->have_state) return fail(ctx, TSAR_ERR_STATE, "no plane state: call tsar_pm_init, tsar_load_planes or tsar_set_plane first")
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != TSAR_OK) return rc_; } while (0)
+
+template <typename T>
+struct TmpIn {   // device view of a caller buffer (copies host buffers in)
+    tsar_ctx* ctx;
+    const T* d = nullptr;
+    T* owned = nullptr;
+    int rc = TSAR_OK;
+    TmpIn(tsar_ctx* c, const T* src, size_t n, int mem) : ctx(c) {
+        if (!src) return;
+        if (mem == TSAR_MEM_DEVICE) { d = src; return; }
+        rc = dev_alloc(ctx, &owned, n);
+        if (rc == TSAR_OK && hipMemcpyAsync(owned, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "H2D failed");
+        d = owned;
+    }
+    ~TmpIn() {
+        if (owned) { hipStreamSynchronize(ctx->stream); hipFree(owned); }
+    }
+};
 
 static void inv3(const double* m, double* o) {
     const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
@@ -169,7 +188,13 @@ static int upload_scene(tsar_ctx* ctx) {
 }
 
 // ---- lifecycle -----------------------------------------------------------------------------------
-extern "C" const char* tsar_version(void) { return "tsar-mvs_amd 0.1.0 (gfx950)"; }
+extern "C" const char* tsar_version(void) {
+#ifdef TSAR_EXPERIMENTS
+    return "tsar-mvs_amd 0.2.0 (gfx950) +experiments";
+#else
+    return "tsar-mvs_amd 0.2.0 (gfx950)";
+#endif
+}
 
 extern "C" int tsar_create(int device, tsar_ctx** out) {
     if (!out) return TSAR_ERR_INVALID;
@@ -183,7 +208,9 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TSAR_ERR_HIP; }
     tsar_default_params(&ctx->params);
+#ifdef TSAR_EXPERIMENTS
     if (const char* e = getenv("TSAR_LDS_SWEEP")) ctx->lds_sweep = e[0] == '1';
+#endif
     ctx->variant = probe_d16_hi_zeroes(ctx) ? 58 : 50;
     if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
     if (const char* e = getenv("TSAR_STRIP")) ctx->strip_w = atoi(e);
@@ -254,7 +281,13 @@ extern "C" int tsar_set_params(tsar_ctx* ctx, const tsar_params* p) {
     CHECK_CTX(ctx);
     if (!p) return fail(ctx, TSAR_ERR_INVALID, "params is NULL");
     if (p->box_hsize < 1 || p->box_vsize < 1 || p->box_hsize > 63 || p->box_vsize > 63) return fail(ctx, TSAR_ERR_INVALID, "box size must be in 1..63");
-    if (p->n_best < 1) return fail(ctx, TSAR_ERR_INVALID, "n_best must be >= 1");
+    if (p->n_best < 1 || p->n_best > TSAR_MAX_SELECTED) return fail(ctx, TSAR_ERR_INVALID, "n_best must be in 1..32 (the reference's costVector holds 32 views, gipuma.cu:467)");
+    {
+        // the hoisted bilateral weights live in LDS, (hrad+1)(vrad+1) taps x 256 threads x 4 B, beside the reference window
+        const int hr = (p->box_hsize - 1) / 2, vr = (p->box_vsize - 1) / 2;
+        const size_t lds = (size_t)(hr + 1) * (vr + 1) * 1024 + (size_t)(32 + 2 * hr) * (16 + 2 * vr) * 4 + 16;
+        if (lds > 160 * 1024) return fail(ctx, TSAR_ERR_INVALID, "box too large: its weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
+    }
     if (p->cost_comb < TSAR_COMB_ALL || p->cost_comb > TSAR_COMB_GOOD) return fail(ctx, TSAR_ERR_INVALID, "cost_comb must be one of TSAR_COMB_ALL / BEST_N / ANGLE / GOOD");
     if (!(p->depth_min > 0.f) || !(p->depth_max > p->depth_min)) return fail(ctx, TSAR_ERR_INVALID, "need 0 < depth_min < depth_max");
     if (!(p->cam_scale > 0.f)) return fail(ctx, TSAR_ERR_INVALID, "cam_scale must be > 0");
@@ -274,6 +307,7 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
     if (n_views < 2 || n_views > TSAR_MAX_VIEWS) return fail(ctx, TSAR_ERR_INVALID, "n_views must be in 2..TSAR_MAX_VIEWS");
     if (w < 8 || h < 8 || (int64_t)w * h > (int64_t)1 << 28) return fail(ctx, TSAR_ERR_INVALID, "image size out of range");
+    if (w + 2 >= (1 << 23) || h + 2 >= (1 << 23)) return fail(ctx, TSAR_ERR_INVALID, "image side too long for the 24-bit quad addressing (w + 2, h + 2 < 2^23)");
     if (!gray || !cams) return fail(ctx, TSAR_ERR_INVALID, "gray/cams is NULL");
     for (int v = 0; v < n_views; v++)
         if (!gray[v]) return fail(ctx, TSAR_ERR_INVALID, "gray[v] is NULL");
@@ -288,8 +322,12 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     sc.w = w; sc.h = h; sc.quad_pitch = w + 2;
     ctx->img.assign(n_views, nullptr);
     ctx->quad.assign(n_views, nullptr);
-    int* dflag = nullptr;
-    TRY(dev_alloc(ctx, &dflag, 1));
+    struct DevInt {   // freed on every exit path
+        int* p = nullptr;
+        ~DevInt() { if (p) hipFree(p); }
+    } dflag_owner;
+    TRY(dev_alloc(ctx, &dflag_owner.p, 1));
+    int* const dflag = dflag_owner.p;
     hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream);
     for (int v = 0; v < n_views; v++) {
         TRY(dev_alloc(ctx, &ctx->img[v], np));
@@ -300,14 +338,13 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     int hflag = 0;
     TSAR_HIP_TRY(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipFree(dflag);
     sc.use_quad = hflag ? 0 : 1;
     for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; }
     if (!sc.use_quad)
         for (auto& q : ctx->quad) dev_free(q);
     derive_cameras(ctx, cams);
     fill_scene_params(ctx);
-    sc.n_sel = n_views - 1;
+    sc.n_sel = std::min(n_views - 1, TSAR_MAX_SELECTED);   // default subset: the first 32 source views at most (tsar_set_view_subset picks others)
     for (int i = 0; i < sc.n_sel; i++) sc.sel[i] = i + 1;
     // state planes (LineState::resize linestate.h:71-110)
     for (int b = 0; b < 2; b++) {
@@ -332,11 +369,14 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
 extern "C" int tsar_set_view_subset(tsar_ctx* ctx, int n, const int32_t* view_idx) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
-    if (n < 1 || n > TSAR_MAX_VIEWS || !view_idx) return fail(ctx, TSAR_ERR_INVALID, "subset size out of range");
+    if (n < 1 || n > TSAR_MAX_SELECTED || !view_idx) return fail(ctx, TSAR_ERR_INVALID, "subset size must be in 1..32 (the reference's viewSelectionSubset / costVector hold 32, gipuma.cu:467)");
     for (int i = 0; i < n; i++)
         if (view_idx[i] < 1 || view_idx[i] >= ctx->n_views) return fail(ctx, TSAR_ERR_INVALID, "view index must be in 1..n_views-1");
     ctx->hscene.n_sel = n;
     for (int i = 0; i < n; i++) ctx->hscene.sel[i] = view_idx[i];
+    // stored costs were scored under the previous subset: the sweep may no longer skip a neighbour that carries the
+    // pixel's own plane (pm_sweep.hip same_bits shortcut); the reference re-scores it and may accept
+    if (ctx->have_state) ctx->cost_consistent = false;
     return upload_scene(ctx);
 }
 
@@ -397,6 +437,28 @@ extern "C" int tsar_pm_iterate(tsar_ctx* ctx, int iters) {
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_out = false;
     return TSAR_OK;
+}
+
+// The iteration loop with the kernels' `final` argument true (gipuma.cu:1096-1138 take `bool final`; nothing in the
+// snapshot passes true): pixels with text == -1 are not touched, ratio / beview are not written.
+extern "C" int tsar_pm_iterate_final(tsar_ctx* ctx, int iters, const float* text, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    NEED_STATE(ctx);
+    if (iters < 0) return fail(ctx, TSAR_ERR_INVALID, "iters must be >= 0");
+    if (!text) return fail(ctx, TSAR_ERR_INVALID, "text is NULL");
+    const size_t np = (size_t)ctx->w * ctx->h;
+    int rc = TSAR_OK;
+    {
+        TmpIn<float> t(ctx, text, np, mem);
+        TRY(t.rc);
+        ctx->final_text = t.d;
+        rc = pm_sweeps(ctx, 2 * iters, 0, 1, 1);
+        ctx->final_text = nullptr;
+        if (rc == TSAR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "sweep failed");
+    }
+    ctx->have_out = false;
+    return rc;
 }
 
 // Diagnostics entry (not in the reference): one half-iteration with propagation and/or refinement.
@@ -470,23 +532,6 @@ extern "C" int tsar_get_plane(tsar_ctx* ctx, float* planes, float* cost, int32_t
 }
 
 // ---- plane <-> depth -----------------------------------------------------------------------------
-template <typename T>
-struct TmpIn {   // device view of a caller buffer (copies host buffers in)
-    tsar_ctx* ctx;
-    const T* d = nullptr;
-    T* owned = nullptr;
-    int rc = TSAR_OK;
-    TmpIn(tsar_ctx* c, const T* src, size_t n, int mem) : ctx(c) {
-        if (!src) return;
-        if (mem == TSAR_MEM_DEVICE) { d = src; return; }
-        rc = dev_alloc(ctx, &owned, n);
-        if (rc == TSAR_OK && hipMemcpyAsync(owned, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "H2D failed");
-        d = owned;
-    }
-    ~TmpIn() {
-        if (owned) { hipStreamSynchronize(ctx->stream); hipFree(owned); }
-    }
-};
 
 extern "C" int tsar_load_planes(tsar_ctx* ctx, const float* depth, const float* normal_world, int mem) {
     CHECK_CTX(ctx);
@@ -567,6 +612,14 @@ extern "C" int tsar_set_reliable_mask(tsar_ctx* ctx, const float* scale, int mem
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSAR_OK;
 }
+extern "C" int tsar_get_reliable_mask(tsar_ctx* ctx, float* scale, int mem) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    if (!scale) return fail(ctx, TSAR_ERR_INVALID, "scale is NULL");
+    TSAR_HIP_TRY(ctx, hipMemcpyAsync(scale, ctx->scale, (size_t)ctx->w * ctx->h * 4, out_kind(mem), ctx->stream));
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TSAR_OK;
+}
 extern "C" int tsar_getview(tsar_ctx* ctx) {
     CHECK_CTX(ctx);
     NEED_STATE(ctx);
@@ -586,6 +639,18 @@ extern "C" int tsar_set_regions(tsar_ctx* ctx, const int32_t* labels, int n_regi
     NEED_VIEWS(ctx);
     if (!labels || !region_text || n_regions < 1) return fail(ctx, TSAR_ERR_INVALID, "labels/region_text is NULL or n_regions < 1");
     const size_t np = (size_t)ctx->w * ctx->h;
+    {
+        // every label indexes the region tables in update_scale / fake_depth / the RANSAC kernels: check the range
+        // before anything is installed (one pass; a bad label must give TSAR_ERR_INVALID, not a device fault)
+        int32_t lo = 0, hi = 0;
+        if (mem == TSAR_MEM_DEVICE) {
+            TRY(launch_label_range(ctx, labels, np, &lo, &hi));
+        } else {
+            lo = hi = labels[0];
+            for (size_t i = 1; i < np; i++) { lo = std::min(lo, labels[i]); hi = std::max(hi, labels[i]); }
+        }
+        if (lo < 0 || hi >= n_regions) return fail(ctx, TSAR_ERR_INVALID, "a label is outside [0, n_regions)");
+    }
     TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->canny, labels, np * 4, in_kind(mem), ctx->stream));
     TRY(dev_alloc(ctx, &ctx->region_text, (size_t)n_regions));
     TRY(dev_alloc(ctx, &ctx->region_size, (size_t)n_regions));
@@ -625,6 +690,19 @@ extern "C" int tsar_fill_textureless(tsar_ctx* ctx) {   // gipuma_fill gipuma.cu
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_out = true;
     return TSAR_OK;
+}
+
+// ---- pinned host buffers ---------------------------------------------------------------------------
+// Host buffers handed to the library move over PCIe; from pageable memory the runtime stages them through its own
+// bounce buffers (tsar_get_result of a 6048 x 4032 view: 51 ms), from page-locked memory the DMA engine reads / writes
+// them directly.  The host side (tsar_gipuma, bench.py's host_boundary leg) allocates its image and result buffers here.
+extern "C" void* tsar_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void tsar_host_free(void* p) {
+    if (p) hipHostFree(p);
 }
 
 // ---- measurement ---------------------------------------------------------------------------------

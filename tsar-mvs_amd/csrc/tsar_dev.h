@@ -9,6 +9,8 @@
 
 #include "../../include/tsar.h"
 
+#define TSAR_MAX_SELECTED 32   // views scored per hypothesis: the reference's costVector[32] (gipuma.cu:467-468)
+
 // One source view as the kernels read it: pose relative to the reference camera (ref = K[I|0]),
 // reference cameraGeometryUtils.h:270-302 / camera.h:9-33.
 struct DevView {
@@ -88,6 +90,7 @@ struct tsar_ctx {
     float *region_text = nullptr, *region_size = nullptr;
     float4* region_n4 = nullptr;
     int sweeps_done = 0;         // RNG stream counter
+    const float* final_text = nullptr;   // device lines->text while tsar_pm_iterate_final runs (the kernels' `final` mode), else null
     // timing
     bool lds_sweep = false;      // TSAR_LDS_SWEEP=1: LDS-patch form of the sweep (pm_sweep_lds.hip); bit-exact, not yet faster
     int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); tsar_create picks 58 (med3/fract + D16 window loads + clamp-free loop for in-image windows + wave priority) when the D16 probe passes, else 50
@@ -134,3 +137,4 @@ int launch_lrdiff(tsar_ctx* ctx);
 int launch_update_scale(tsar_ctx* ctx);
 int launch_fake_depth(tsar_ctx* ctx);
 int launch_split_out4(tsar_ctx* ctx, float* depth, float* normal3);
+int launch_label_range(tsar_ctx* ctx, const int32_t* labels, size_t n, int32_t* lo, int32_t* hi);   // min / max of a device label plane

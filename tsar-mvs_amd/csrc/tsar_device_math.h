@@ -101,13 +101,12 @@ DEVFN void view_vector(const DevRef& rf, int x, int y, float* v) {
 }
 // getHomography_cu gipuma.cu:207-224: H = K_src (R - t n^T / d) K_ref^-1
 DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n4, float* H) {
-    const float inv_d = 1.0f / n4.w;
     const float n[3] = {n4.x, n4.y, n4.z};
     float M[9], T[9];
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 3; r++)   // outer product, then every element divided by d (matdivide, config.h:139-148)
 #pragma unroll
-        for (int c = 0; c < 3; c++) M[r * 3 + c] = vw.R[r * 3 + c] - (vw.t[r] * n[c]) * inv_d;
+        for (int c = 0; c < 3; c++) M[r * 3 + c] = vw.R[r * 3 + c] - (vw.t[r] * n[c]) / n4.w;
     mat3mul(M, rf.Kinv, T);
     mat3mul(vw.K, T, H);
 }

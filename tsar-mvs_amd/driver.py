@@ -26,19 +26,26 @@ def alloc_gather_buffers(dist, tensors: Sequence, dst: int = 0):
     return [[torch.empty_like(t) for _ in range(dist.get_world_size())] for t in tensors]
 
 
-def gather_results(dist, tensors: Sequence, dst: int = 0, out=None):
+def gather_results(dist, tensors: Sequence, dst: int = 0, out=None, async_op: bool = False):
     """Gather each rank's result tensors to `dst` (RCCL on GPUs, gloo in the CPU tests).
     Returns on dst a list (per tensor) of lists (per rank) — `out` if given (alloc_gather_buffers) —
-    elsewhere None."""
+    elsewhere None.  With async_op=True the collectives are only enqueued (RCCL: on the collective's own
+    stream, so they overlap the next view's kernels) and the list of work handles is returned on every
+    rank instead: wait() on each before `tensors` are overwritten or `out` is read."""
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
-    res = []
+    res, works = [], []
     for k, t in enumerate(tensors):
         if rank == dst:
             bucket = out[k] if out is not None else [torch.empty_like(t) for _ in range(world)]
-            dist.gather(t, bucket, dst=dst)
+            wk = dist.gather(t, bucket, dst=dst, async_op=async_op)
             res.append(bucket)
         else:
-            dist.gather(t, None, dst=dst)
+            wk = dist.gather(t, None, dst=dst, async_op=async_op)
+        works.append(wk)
+    if async_op:
+        if out is None and rank == dst:
+            raise ValueError("async gather needs caller-owned receive buffers (alloc_gather_buffers)")
+        return works
     return res if rank == dst else None
