@@ -124,7 +124,7 @@ def test_cfg2_full_size_properties():
     # which evaluates the same arithmetic with a different instruction selection: fast-mode tolerance)
     planes, c_host, _, _ = m.get_plane()
     c_again, _, _ = m.pm_cost_planes(planes)
-    assert np.max(np.abs(c_again - c_host)) <= 2e-3
+    assert np.max(np.abs(c_again - c_host)) <= 1e-3
     m.close()
 
 

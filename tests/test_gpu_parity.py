@@ -5,7 +5,7 @@ Two arithmetic modes are checked:
   strict (TSAR_FLAG_STRICT_DIV): every operation is a single IEEE fp32 op in the oracle's order, so the
       GPU must reproduce the oracle BIT FOR BIT — planes, costs, best views, after whole iterations.
   fast (default): the per-tap perspective divide uses v_rcp_f32 (1 ulp) instead of two IEEE divisions.
-      Tolerance: |cost_gpu - cost_oracle| <= 2e-3 absolute on the same plane (cost lives in [0, 2]; the
+      Tolerance: |cost_gpu - cost_oracle| <= 1e-3 absolute on the same plane (cost lives in [0, 2]; the
       fp32 cancellation in var = E[x^2]-E[x]^2 amplifies a 1-ulp change of a tap position), and after
       one half-iteration from a common state >= 80 % of the swept pixels end on the bit-identical plane (~85 %
       measured; the late refinement steps perturb a plane so little that accept/reject is a near-tie that
@@ -19,7 +19,7 @@ from tsar_mvs_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
-FAST_COST_ATOL = 2e-3
+FAST_COST_ATOL = 1e-3     # max; the distribution (p50 4e-6, p99 5e-5, max 3e-4 measured) is asserted in test_gpu_fast_mode.py
 
 
 def _oracle(scene, **kw):
@@ -159,8 +159,8 @@ def test_one_sweep_fast_agreement(mid_scene):
     assert same[~swept].all()                                                   # the other colour is not touched
     assert same[swept].mean() >= 0.80, same[swept].mean()
     assert np.max(np.abs(cost - orc.c)[same]) <= FAST_COST_ATOL
-    # where the decision differs the accepted costs are still within the tolerance band of each other
-    assert np.percentile(np.abs(cost - orc.c)[~same], 95) <= 0.05 if (~same).any() else True
+    # pixels that end on another plane are checked in test_gpu_fast_mode.py::test_diverged_pixels_are_valid_patchmatch_steps
+    # (re-scored by the oracle: valid steps, near-ties)
     m.close()
 
 

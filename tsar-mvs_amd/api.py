@@ -287,19 +287,22 @@ class Matcher:
     def depth_to_plane(self):
         self._chk(self.L.tsar_depth_to_plane(self._ctx))
 
-    def get_result(self, want=("depth", "normal", "cost", "confid"), pinned=False):
-        """pinned=True: the result arrays are page-locked (tsar_host_alloc), so the D2H copies run at PCIe rate"""
-        out = {}
+    def get_result(self, want=("depth", "normal", "cost", "confid"), pinned=False, out=None):
+        """pinned=True: the result arrays are page-locked (tsar_host_alloc), so the D2H copies run at PCIe rate.
+        out: dict of caller-owned arrays to fill instead (e.g. page-locked ones allocated once and reused per view)."""
+        shapes = {"depth": (self.h, self.w), "normal": (self.h, self.w, 3), "cost": (self.h, self.w), "confid": (self.h, self.w)}
         empty = pinned_empty if pinned else np.empty
-        depth = empty((self.h, self.w), np.float32) if "depth" in want else None
-        normal = empty((self.h, self.w, 3), np.float32) if "normal" in want else None
-        cost = empty((self.h, self.w), np.float32) if "cost" in want else None
-        confid = empty((self.h, self.w), np.float32) if "confid" in want else None
-        self._chk(self.L.tsar_get_result(self._ctx, _ptr(depth)[0], _ptr(normal)[0], _ptr(cost)[0], _ptr(confid)[0], MEM_HOST))
-        for k, v in (("depth", depth), ("normal", normal), ("cost", cost), ("confid", confid)):
-            if v is not None:
-                out[k] = v
-        return out
+        res = {}
+        for k in ("depth", "normal", "cost", "confid"):
+            if out is not None and k in out:
+                a = out[k]
+                assert a.dtype == np.float32 and tuple(a.shape) == shapes[k] and a.flags["C_CONTIGUOUS"]
+                res[k] = a
+            elif out is None and k in want:
+                res[k] = empty(shapes[k], np.float32)
+        self._chk(self.L.tsar_get_result(self._ctx, _ptr(res.get("depth"))[0], _ptr(res.get("normal"))[0], _ptr(res.get("cost"))[0],
+                                         _ptr(res.get("confid"))[0], MEM_HOST))
+        return res
 
     def get_result_device(self, depth=None, normal=None, cost=None, confid=None):
         """Write results into caller-provided torch CUDA tensors."""
@@ -457,7 +460,9 @@ def fuse(depths, normals, grays, K, R, t, pairs, params: FusionParams | None = N
 
 
 def pinned_empty(shape, dtype=np.float32):
-    """numpy array over page-locked host memory from tsar_host_alloc (freed when the array is collected)"""
+    """numpy array over page-locked host memory from tsar_host_alloc; the memory is released when the last array
+    (or view of it) referring to it is collected"""
+    import weakref
     L = load_library()
     dt = np.dtype(dtype)
     n = int(np.prod(shape)) * dt.itemsize
@@ -465,15 +470,5 @@ def pinned_empty(shape, dtype=np.float32):
     if not p:
         raise MemoryError(f"tsar_host_alloc({n}) failed")
     buf = (C.c_char * n).from_address(p)
-    arr = np.frombuffer(buf, dtype=dt).reshape(shape)
-
-    class _Owner:
-        def __del__(self, p=p, L=L):
-            L.tsar_host_free(p)
-    _owners[id(buf)] = (_Owner(), buf)
-    import weakref
-    weakref.finalize(arr, _owners.pop, id(buf), None)
-    return arr
-
-
-_owners = {}
+    weakref.finalize(buf, L.tsar_host_free, p)      # every numpy view keeps `buf` alive through its base chain
+    return np.frombuffer(buf, dtype=dt).reshape(shape)
