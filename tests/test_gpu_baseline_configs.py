@@ -128,6 +128,25 @@ def test_cfg2_full_size_properties():
     m.close()
 
 
+@pytest.mark.parametrize("variant", ["114"])
+def test_tap_loop_without_d16_loads_bit_exact(monkeypatch, variant):
+    """the tap-loop variant tsar_create falls back to when the D16 probe fails (no ds_read_u16_d16_hi): forced here"""
+    monkeypatch.setenv("TSAR_VARIANT", variant)
+    sc = synth.make_scene(192, 128, 4, seed=11)
+    orc = _oracle(sc, seed=19)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    m = api.matcher_from_scene(sc, seed=19, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(2)
+    _assert_state_equal(m, orc)
+    m.close()
+    f = api.matcher_from_scene(sc, seed=19)
+    c_fast, _, _ = f.pm_cost_planes(orc.norm4.copy())
+    f.close()
+    assert np.max(np.abs(c_fast - orc.c)) <= 1e-3
+
+
 def test_lds_patch_sweep_variant_bit_exact(monkeypatch):
     """the opt-in LDS-patch form of the sweep (pm_sweep_lds.hip, TSAR_LDS_SWEEP=1): slower than the default kernel
      but kept as a measured alternative — it must produce the oracle's bits too"""

@@ -139,6 +139,11 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //   bit 4: fast mode, radius 5 — clamp-free tap loop for waves whose windows project inside the source image (-1 %)
 //   bit 5: fast mode, radius 5 — s_setprio 3 while a wave computes tap positions and issues its gathers, 0 while it
 //          blends: gathers enter the memory system earlier (-1.1 %; the opposite assignment costs +2.6 %)
+//   bit 6: radius 5 — the view's quad-texture base (border offset folded in) is pinned in an SGPR pair for the whole view
+//          (the compiler otherwise re-loads it with s_load in every column and waits for it, and for the column's LDS
+//          loads, right before issuing the gathers), the tap's byte offset is a plain shift, and the column's six
+//          bilateral weights are loaded at the top of the column with its reference texels instead of one LDS round trip
+//          per pair of taps inside the blend phase
 template <int HR, bool STRICT, bool QUAD, int V = 0>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
                       const PixelRef& pr, int x, int y, const float4& n4) {
@@ -163,18 +168,38 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             const float X = fma_(H[1], yj, fma_(H[0], xi, H[2])), Y = fma_(H[4], yj, fma_(H[3], xi, H[5])), Z = fma_(H[7], yj, fma_(H[6], xi, H[8]));
             const float rz = __builtin_amdgcn_rcpf(Z);
             const float u = X * rz, v = Y * rz;
-            inside = inside && Z > 0.0f && u >= 0.0f && u <= (float)(w - 1) && v >= 0.0f && v <= (float)(h - 1);
+            // variant bit 6 addresses the texture from entry (1, 1) with an unsigned offset: its clamp-free loop must never see
+            // floor(u) = -1, so the corners keep one pixel of margin (rounding moves a tap by ~1e-4 pixel at most)
+            const float mg = (V & 64) ? 1.0f : 0.0f;
+            inside = inside && Z > 0.0f && u >= mg && u <= (float)(w - 1) - mg && v >= mg && v <= (float)(h - 1) - mg;
         }
         need_clamp = !__all(inside);
     }
     // One window column (six taps) of the production loop, written in three explicit phases — all six tap positions,
     // then all six gathers, then unpack / blend / accumulate — so that six gathers are in flight per wave whatever
     // the instruction scheduler decides (it keeps source order when a reordering would cost registers).
+    // variant bit 6: quad base + border offset, opaque to the optimiser so that it stays in two SGPRs across the view
+    uint32_t qb_lo = 0, qb_hi = 0;
+    if (V & 64) {
+        const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)qorg;
+        qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qa);
+        qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32));
+        asm volatile("" : "+s"(qb_lo), "+s"(qb_hi));
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto column_fast = [&](int i, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         const float xi = (float)(x + i);
         const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
         float rcol[6];
+        f32x2 wcol[3];
+        if (V & 64) {
+            // the column's six weights, [tap][thread] layout: taps are 1 KiB apart = 4 units of ds_read2st64's 256-byte stride
+            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + tap * PM_BLOCK);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(8 * k), "n"(8 * k + 4), "v"(bz));
+        }
         if (V & 8) {
             // the column's six reference texels, each loaded into bits 31:16 of a register = its fp32 value.  gfx950 runs
             // with SRAM ECC, where a D16 load writes the whole register (zeros in the other half); tsar_create probes
@@ -197,12 +222,17 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
             float u, v;
             int iu, iv;
+            // Clamp range.  The oracle clamps to [-1, w] (tex2D at u + .5 with clamp addressing).  With variant bit 6 the byte
+            // offset is unsigned from entry (1, 1), so floor(u) must be >= 0: clamp to [0, w - 1] instead.  The sample is the same
+            // bit for bit: for u in [-1, 0) both texels of the pair are T(0) (edge replication), so the blend returns T(0) whatever
+            // the fraction — exactly what u = 0 returns (fraction 0); likewise beyond w - 1, and per axis.
+            const float ulo = (V & 64) ? 0.0f : -1.0f, uhi = (V & 64) ? (float)(w - 1) : (float)w, vhi = (V & 64) ? (float)(h - 1) : (float)h;
             if (STRICT) {                                       // the oracle's operations: IEEE divides, min/max clamp, floor / subtract
                 u = X / Z;
                 v = Y / Z;
                 if (CLAMP) {
-                    u = fminf(fmaxf(u, -1.0f), (float)w);
-                    v = fminf(fmaxf(v, -1.0f), (float)h);
+                    u = fminf(fmaxf(u, ulo), uhi);
+                    v = fminf(fmaxf(v, ulo), vhi);
                 }
                 const float fu = floorf(u), fv = floorf(v);
                 ax[jj] = u - fu;
@@ -214,8 +244,8 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 u = X * rz;
                 v = Y * rz;
                 if (CLAMP) {
-                    u = __builtin_amdgcn_fmed3f(u, -1.0f, (float)w);
-                    v = __builtin_amdgcn_fmed3f(v, -1.0f, (float)h);
+                    u = __builtin_amdgcn_fmed3f(u, ulo, uhi);
+                    v = __builtin_amdgcn_fmed3f(v, ulo, vhi);
                 }
                 ax[jj] = __builtin_amdgcn_fractf(u);
                 ay[jj] = __builtin_amdgcn_fractf(v);
@@ -226,9 +256,12 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             // folded into the uniform constant (qp + 1) * 4
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-            uint32_t off;
-            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
-            if (V & 4) q[jj] = off * 2654435761u;               // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
+            uint32_t off = 0;
+            if (!(V & 64)) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
+            if (V & 64) {                                       // base already holds the border offset: the byte offset is a plain shift
+                const uint32_t off2 = (uint32_t)lin << 2;
+                q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off2);
+            } else if (V & 4) q[jj] = off * 2654435761u;        // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
             else q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
         }
         if (V & 16) __builtin_amdgcn_sched_barrier(0);           // nothing of phase 3 may move above the last gather
@@ -244,7 +277,18 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             const float bot = fma_(ax[jj], t11 - t01, t01);
             float s = fma_(ay[jj], bot - top, top);
             float r;
-            if (V & 8) {
+            if (V & 64) {
+                // one wait per column, at its first tap: every LDS load of the column (six texels when they are D16 loads,
+                // three weight pairs) was issued before the gathers, in order, and has long returned when the first gather does
+                if (jj == 0) {
+                    if (V & 8)
+                        asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[0]), "+v"(rcol[1]), "+v"(rcol[2]), "+v"(rcol[3]), "+v"(rcol[4]), "+v"(rcol[5]),
+                            "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(s));
+                    else
+                        asm("s_waitcnt lgkmcnt(0)" : "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(s));
+                }
+                r = (V & 8) ? rcol[jj] : tile_value(tile[own + (2 * jj - 5) * tw + i]);
+            } else if (V & 8) {
                 // tied to s so that the wait cannot be scheduled ahead of the gather's return, by which time the LDS
                 // loads issued at the top of the column have long completed
                 asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[jj]), "+v"(s));
@@ -252,7 +296,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             } else {
                 r = tile_value(tile[own + (2 * jj - 5) * tw + i]);
             }
-            const float wt = wts[(tap + jj) * PM_BLOCK];
+            const float wt = (V & 64) ? wcol[jj >> 1][jj & 1] : wts[(tap + jj) * PM_BLOCK];
             const float ws = wt * s;
             sum_src += ws;
             sum_src_src = fma_(ws, s, sum_src_src);

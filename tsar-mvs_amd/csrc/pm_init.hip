@@ -90,10 +90,10 @@ template <int NB, int HR, bool INIT>
 static int launch_full_nh(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
     // the production configuration (8-bit quad textures, box 11, <= 2 best views) runs the sweep's tap loop (pm_core.h view_cost,
-    // variant 58 / 50) in both arithmetic modes
-    if (quad && NB == 2 && HR == 5 && (ctx->variant == 58 || ctx->variant == 50)) {
-        if (strict) return ctx->variant == 58 ? launch_full_t<2, 5, true, true, INIT, 58>(ctx, planes, c, n, bv, rt) : launch_full_t<2, 5, true, true, INIT, 50>(ctx, planes, c, n, bv, rt);
-        return ctx->variant == 58 ? launch_full_t<2, 5, false, true, INIT, 58>(ctx, planes, c, n, bv, rt) : launch_full_t<2, 5, false, true, INIT, 50>(ctx, planes, c, n, bv, rt);
+    // variant 122 / 114) in both arithmetic modes
+    if (quad && NB == 2 && HR == 5 && (ctx->variant == 122 || ctx->variant == 114)) {
+        if (strict) return ctx->variant == 122 ? launch_full_t<2, 5, true, true, INIT, 122>(ctx, planes, c, n, bv, rt) : launch_full_t<2, 5, true, true, INIT, 114>(ctx, planes, c, n, bv, rt);
+        return ctx->variant == 122 ? launch_full_t<2, 5, false, true, INIT, 122>(ctx, planes, c, n, bv, rt) : launch_full_t<2, 5, false, true, INIT, 114>(ctx, planes, c, n, bv, rt);
     }
     if (strict) return quad ? launch_full_t<NB, HR, true, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, true, false, INIT>(ctx, planes, c, n, bv, rt);
     return quad ? launch_full_t<NB, HR, false, true, INIT>(ctx, planes, c, n, bv, rt) : launch_full_t<NB, HR, false, false, INIT>(ctx, planes, c, n, bv, rt);

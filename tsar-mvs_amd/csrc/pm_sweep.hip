@@ -263,27 +263,39 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
 template <int NB, int HR>
 static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
-    if (strict) {
-        // the production tap loop also exists in the oracle's arithmetic (IEEE divides, min/max, floor): same bits as the
-        // generic strict kernel, with the D16 window loads, the clamp-free loop and the gather-phase priority
-        if (quad && NB == 2 && HR == 5 && ctx->variant == 58) return launch_sweep_t<2, 5, true, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
-        if (quad && NB == 2 && HR == 5 && ctx->variant == 50) return launch_sweep_t<2, 5, true, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
-        return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
-    }
-    if (quad && NB == 2 && HR == 5) {   // the production configuration: code-generation variants (TSAR_VARIANT)
-        switch (ctx->variant) {
-#ifdef TSAR_EXPERIMENTS   // diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1); the product carries 50 and 58 only
-            case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
-            case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
-            case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
-            case 18: return launch_sweep_t<2, 5, false, true, 18>(ctx, colour, a, b, c, sid, dp, dr);
-            case 26: return launch_sweep_t<2, 5, false, true, 26>(ctx, colour, a, b, c, sid, dp, dr);
+    // The production configuration (8-bit quad textures, box 11, <= 2 best views) runs the hand-scheduled tap loop of
+    // pm_core.h view_cost, in both arithmetic modes: variant 122 (114 where the D16 probe fails).  In strict mode it is
+    // the oracle's arithmetic (IEEE divides, min/max, floor) with the same loads, clamp-free loop and priorities: same
+    // bits as the generic strict kernel.
+    if (quad && NB == 2 && HR == 5) {
+        if (strict) {
+            switch (ctx->variant) {
+                case 122: return launch_sweep_t<2, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+                case 114: return launch_sweep_t<2, 5, true, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
+#ifdef TSAR_EXPERIMENTS
+                case 58: return launch_sweep_t<2, 5, true, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
+                case 50: return launch_sweep_t<2, 5, true, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
 #endif
-            case 50: return launch_sweep_t<2, 5, false, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
-            case 58: return launch_sweep_t<2, 5, false, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
-            default: break;
+                default: break;
+            }
+        } else {
+            switch (ctx->variant) {
+                case 122: return launch_sweep_t<2, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+                case 114: return launch_sweep_t<2, 5, false, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
+#ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
+                case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
+                case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
+                case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
+                case 18: return launch_sweep_t<2, 5, false, true, 18>(ctx, colour, a, b, c, sid, dp, dr);
+                case 26: return launch_sweep_t<2, 5, false, true, 26>(ctx, colour, a, b, c, sid, dp, dr);
+                case 50: return launch_sweep_t<2, 5, false, true, 50>(ctx, colour, a, b, c, sid, dp, dr);
+                case 58: return launch_sweep_t<2, 5, false, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
+#endif
+                default: break;
+            }
         }
     }
+    if (strict) return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
     return quad ? launch_sweep_t<NB, HR, false, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, false, false>(ctx, colour, a, b, c, sid, dp, dr);
 }
 

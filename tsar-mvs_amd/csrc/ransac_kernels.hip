@@ -4,10 +4,11 @@
 //
 // MI355X shape: (1) the reliable pixels of all textureless regions are compacted in raster order by a
 // device select + a stable radix sort by region (rocPRIM; plain library primitives), (2) one kernel
-// back-projects them to 3-D points, (3) ONE 1024-thread workgroup per region runs the whole
-// sequential hypothesise / count / adapt-threshold / perturb loop with block-wide inlier counts,
-// every region on its own CU concurrently.  Arithmetic is double precision in the reference's
-// operation order, so the result is reproducible bit for bit on the CPU oracle.
+// back-projects them to 3-D points, (3) the fit: the 10 000 three-point hypotheses are counted on
+// 125 workgroups per region and phase, the 4 000 sequential perturbation steps on one workgroup per
+// region with a lookahead that shares each pass over the points between the candidate planes of
+// several steps (see "the fit, spread over the chip" below).  Arithmetic is double precision in the
+// reference's operation order, so the result is reproducible bit for bit on the CPU oracle.
 //
 // Deterministic choices (the reference uses rand() and a time-seeded shuffle): raster-order point
 // lists, even subsampling to 49999 points above 50000, Philox draws keyed by (draw, stage, region).
@@ -73,10 +74,29 @@ DEVFN void philox_raw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32
 }
 DEVFN uint32_t rnd_index(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
 
-// block-wide number of points with |ax + by + cz + d| < thr
+// ---- the fit, spread over the chip ---------------------------------------------------------------------
+// The reference's loop (main.cpp:1603-1711) is sequential only in how it COMPARES inlier counts:
+//   stage 1: 10 000 three-point hypotheses; between two threshold adaptations (every 1 000) the inlier threshold is
+//            fixed, so the 999 counts of a phase are independent of each other.  ransac_count_kernel evaluates them on
+//            125 workgroups per region (8 hypotheses share each pass over the points), ransac_adapt_kernel then replays the
+//            sequential accept rule on the stored counts — `cnt >= maximum` in index order picks the LAST hypothesis that
+//            attains the phase's maximum count — and performs the adaptation step (hypothesis 1000 j, the `max2` re-count).
+//   stage 2: 1 000 rounds x 4 perturbation scales, each perturbing the current best plane: truly sequential, one
+//            workgroup per region.  ransac_refine_kernel looks G steps ahead: the 2^G - 1 candidate planes of every
+//            accept / reject history of the next G steps are counted in ONE pass over the points (the pass, not the
+//            arithmetic, is what a step costs: 600 KB of points stream from L2 each time), then the G decisions are
+//            replayed in order on the counts.  Same planes, same counts, same decisions as the sequential loop.
+// State between kernels lives in RansacState (one per region slot); counts in cnt[slot][1000].
+struct RansacState {
+    double pl[4];          // best plane so far (a, b, c, d)
+    int maximum;           // its inlier count
+    float depth_abs_f;     // inlier threshold, kept as the float the reference keeps (main.cpp:1551-1552)
+};
+
+template <int BS>
 DEVFN int block_count(const float* __restrict__ pts, int n, double a, double b, double c, double d, double thr, int* sh) {
     int cnt = 0;
-    for (int i = threadIdx.x; i < n; i += RS_BLOCK) {
+    for (int i = threadIdx.x; i < n; i += BS) {
         const double resid = fabs((double)pts[3 * i] * a + (double)pts[3 * i + 1] * b + (double)pts[3 * i + 2] * c + d);
         cnt += resid < thr;
     }
@@ -87,142 +107,260 @@ DEVFN int block_count(const float* __restrict__ pts, int n, double a, double b, 
     __syncthreads();
     int tot = 0;
 #pragma unroll
-    for (int wv = 0; wv < RS_BLOCK / 64; wv++) tot += sh[wv];
+    for (int wv = 0; wv < BS / 64; wv++) tot += sh[wv];
     return tot;
 }
 
-// The same count for RS_BATCH planes in one pass over the points: the hypotheses between two threshold adaptations
-// are independent of each other (only their counts are compared afterwards, in order), so a batch shares the point
-// loads (600 KB per region per pass, from L2) and the two barriers.
-#define RS_BATCH 8
-DEVFN void block_count_batch(const float* __restrict__ pts, int n, const double (*pl)[4], int nb, double thr, int (*shb)[RS_BATCH], int* out) {
-    int cnt[RS_BATCH];
+// The same count for NB planes in one pass over the points; pl in LDS (every thread reads all of them).
+template <int BS, int NB>
+DEVFN void block_count_batch(const float* __restrict__ pts, int n, const double (*pl)[4], double thr, int (*shb)[NB], int* out) {
+    double P[NB][4];
 #pragma unroll
-    for (int q = 0; q < RS_BATCH; q++) cnt[q] = 0;
-    for (int i = threadIdx.x; i < n; i += RS_BLOCK) {
+    for (int q = 0; q < NB; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) P[q][e] = pl[q][e];
+    int cnt[NB];
+#pragma unroll
+    for (int q = 0; q < NB; q++) cnt[q] = 0;
+    for (int i = threadIdx.x; i < n; i += BS) {
         const double px = (double)pts[3 * i], py = (double)pts[3 * i + 1], pz = (double)pts[3 * i + 2];
 #pragma unroll
-        for (int q = 0; q < RS_BATCH; q++) {
-            const double resid = fabs(px * pl[q][0] + py * pl[q][1] + pz * pl[q][2] + pl[q][3]);
+        for (int q = 0; q < NB; q++) {
+            const double resid = fabs(px * P[q][0] + py * P[q][1] + pz * P[q][2] + P[q][3]);
             cnt[q] += resid < thr;
         }
     }
 #pragma unroll
-    for (int q = 0; q < RS_BATCH; q++)
+    for (int q = 0; q < NB; q++)
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) cnt[q] += __shfl_down(cnt[q], o);
     __syncthreads();                       // previous readers of shb are done
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int q = 0; q < RS_BATCH; q++) shb[threadIdx.x >> 6][q] = cnt[q];
+        for (int q = 0; q < NB; q++) shb[threadIdx.x >> 6][q] = cnt[q];
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < RS_BATCH; q++) {
+    for (int q = 0; q < NB; q++) {
         int tot = 0;
 #pragma unroll
-        for (int wv = 0; wv < RS_BLOCK / 64; wv++) tot += shb[wv][q];
+        for (int wv = 0; wv < BS / 64; wv++) tot += shb[wv][q];
         out[q] = tot;
     }
 }
 
-__global__ __launch_bounds__(RS_BLOCK) void ransac_fit_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
-                                                              const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
-                                                              const float* __restrict__ region_size, uint32_t k0, uint32_t k1, uint32_t flags,
-                                                              float4* __restrict__ region_n4, float* __restrict__ inlier_ratio) {
-    __shared__ int sh[RS_BLOCK / 64];
-    __shared__ int shb[RS_BLOCK / 64][RS_BATCH];
-    __shared__ double shpl[RS_BATCH][4];
+// hypothesis k of main.cpp:1603-1640: three Philox-drawn points -> unit plane (calcLinePara main.cpp:147-164)
+DEVFN void ransac_hypothesis(const float* __restrict__ pts, int n, int rg, int k, uint32_t k0, uint32_t k1, uint32_t flags, double* pl) {
+    uint32_t r[4];
+    philox_raw((uint32_t)k, 0x52414E53u, (uint32_t)rg, k0, k1, r);
+    const float* p1 = pts + 3 * rnd_index(r[0], (uint32_t)n);
+    const float* p2 = pts + 3 * rnd_index(r[1], (uint32_t)n);
+    const float* p3 = pts + 3 * rnd_index(r[2], (uint32_t)n);
+    const double x1 = p1[0], y1 = p1[1], z1 = p1[2], x2 = p2[0], y2 = p2[1], z2 = p2[2], x3 = p3[0], y3 = p3[1], z3 = p3[2];
+    // calcLinePara main.cpp:159: the first component is written with (y3 - y1) twice
+    double ta = (flags & TSAR_FLAG_FIX_PLANE_FIT) ? (y2 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1) : (y3 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1);
+    double tb = (x3 - x1) * (z2 - z1) - (x2 - x1) * (z3 - z1);
+    double tc = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1);
+    double td = -(ta * x1 + tb * y1 + tc * z1);
+    const double sq = sqrt(ta * ta + tb * tb + tc * tc);
+    pl[0] = ta / sq; pl[1] = tb / sq; pl[2] = tc / sq; pl[3] = td / sq;
+}
+
+#define RS_PHASE 1000            // hypotheses between two threshold adaptations (main.cpp:1642)
+#define RS_BATCH 8               // hypotheses sharing one pass over the points in ransac_count_kernel
+#define RS_COUNT_BLOCK 256
+#define RS_BATCHES ((RS_PHASE - 1 + RS_BATCH - 1) / RS_BATCH)     // 125 workgroups per region and phase
+
+// Sequential accept rule over the stored counts of hypotheses base+1 .. base+999: `if (cnt >= maximum)` in index order ends
+// on the last index attaining max(maximum, max cnt).  Returns that index (or -1) to every thread; *best_cnt its count.
+DEVFN int replay_phase(const int* __restrict__ cnt, int maximum, int* sh_val, int* sh_idx, int* best_cnt) {
+    int v = -1, ix = -1;
+    for (int i = 1 + (int)threadIdx.x; i < RS_PHASE; i += RS_BLOCK) {
+        const int c = cnt[i];
+        if (c > v || (c == v && i > ix)) { v = c; ix = i; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int v2 = __shfl_down(v, o), i2 = __shfl_down(ix, o);
+        if (v2 > v || (v2 == v && i2 > ix)) { v = v2; ix = i2; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh_val[threadIdx.x >> 6] = v; sh_idx[threadIdx.x >> 6] = ix; }
+    __syncthreads();
+    v = -1; ix = -1;
+#pragma unroll
+    for (int wv = 0; wv < RS_BLOCK / 64; wv++) {
+        const int v2 = sh_val[wv], i2 = sh_idx[wv];
+        if (v2 > v || (v2 == v && i2 > ix)) { v = v2; ix = i2; }
+    }
+    *best_cnt = v;
+    return (ix >= 0 && v >= maximum) ? ix : -1;
+}
+
+// phase j = 0..9: (j > 0) replay the counts of hypotheses 1000(j-1)+1 .. 1000 j - 1, then the adaptation step k = 1000 j
+// (main.cpp:1603-1662).  One 1024-thread workgroup per region slot.
+__global__ __launch_bounds__(RS_BLOCK) void ransac_adapt_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
+                                                                const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
+                                                                const float* __restrict__ region_size, uint32_t k0, uint32_t k1, uint32_t flags,
+                                                                RansacState* __restrict__ state, const int* __restrict__ cnt_all, int phase) {
+    __shared__ int sh[RS_BLOCK / 64], sh2[RS_BLOCK / 64];
     const int slot = blockIdx.x;
     const int rg = region_of_slot[slot];
     const int n = pts_count[slot];
     const float* __restrict__ pts = pts_all + 3 * (size_t)pts_start[slot];
-    double a = 0, b = 0, c = 1, d = -1;
-    int maximum = 0;
+    RansacState st;
+    if (phase == 0) {
+        st.pl[0] = 0; st.pl[1] = 0; st.pl[2] = 1; st.pl[3] = -1;
+        st.maximum = 0;
+        st.depth_abs_f = (float)(0.0003 * (double)sqrtf(region_size[rg] / 20));    // `float depth_abs = 0.0003 * sqrtf(size / 20)` main.cpp:1551-1552
+    } else {
+        st = state[slot];
+    }
     if (n > 0) {
-        // `float depth_abs = 0.0003 * sqrtf(size / 20)` main.cpp:1551-1552
-        float depth_abs_f = (float)(0.0003 * (double)sqrtf(region_size[rg] / 20));
-        double depth_abs = depth_abs_f;
-        // hypothesis k of main.cpp:1603-1640: three Philox-drawn points -> unit plane (calcLinePara main.cpp:147-164)
-        auto hypothesis = [&](int k, double* pl) {
-            uint32_t r[4];
-            philox_raw((uint32_t)k, 0x52414E53u, (uint32_t)rg, k0, k1, r);
-            const float* p1 = pts + 3 * rnd_index(r[0], (uint32_t)n);
-            const float* p2 = pts + 3 * rnd_index(r[1], (uint32_t)n);
-            const float* p3 = pts + 3 * rnd_index(r[2], (uint32_t)n);
-            const double x1 = p1[0], y1 = p1[1], z1 = p1[2], x2 = p2[0], y2 = p2[1], z2 = p2[2], x3 = p3[0], y3 = p3[1], z3 = p3[2];
-            // calcLinePara main.cpp:159: the first component is written with (y3 - y1) twice
-            double ta = (flags & TSAR_FLAG_FIX_PLANE_FIT) ? (y2 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1) : (y3 - y1) * (z3 - z1) - (z2 - z1) * (y3 - y1);
-            double tb = (x3 - x1) * (z2 - z1) - (x2 - x1) * (z3 - z1);
-            double tc = (x2 - x1) * (y3 - y1) - (x3 - x1) * (y2 - y1);
-            double td = -(ta * x1 + tb * y1 + tc * z1);
-            const double sq = sqrt(ta * ta + tb * tb + tc * tc);
-            pl[0] = ta / sq; pl[1] = tb / sq; pl[2] = tc / sq; pl[3] = td / sq;
-        };
-        for (int k = 0; k < 10000;) {                                       // main.cpp:1603-1662
-            if (k % 1000 == 0) {
-                double pl[4];
-                hypothesis(k, pl);
-                const int cnt = block_count(pts, n, pl[0], pl[1], pl[2], pl[3], depth_abs, sh);
-                if (cnt >= maximum) { a = pl[0]; b = pl[1]; c = pl[2]; d = pl[3]; maximum = cnt; }
-                // adaptive inlier threshold, main.cpp:1642-1661
-                const double rat = (double)maximum / (double)n;
-                if (rat < 0.3 && depth_abs < 0.003) {
-                    depth_abs_f = (float)((double)depth_abs_f + 0.0001);
-                    depth_abs = depth_abs_f;
-                } else {
-                    const int max2 = block_count(pts, n, a, b, c, d, (double)depth_abs_f + 0.0001, sh);
-                    if ((double)max2 > (double)maximum + (double)n * 0.02) {
-                        depth_abs_f = (float)((double)depth_abs_f + 0.0001);
-                        depth_abs = depth_abs_f;
-                        maximum = max2;
-                    }
-                }
-                k++;
-            } else {                                                        // up to the next adaptation the threshold is fixed
-                const int nb = min(RS_BATCH, 1000 - k % 1000);
-                double pl[RS_BATCH][4];
-                int cnt[RS_BATCH];
-                // one thread per hypothesis of the batch builds its plane (three dependent point loads, a double sqrt and
-                // four divisions: ~3 us of latency each if every thread did all eight in turn), then all threads pick them up
-                if (threadIdx.x < RS_BATCH) {
-                    double mine[4];
-                    hypothesis(k + ((int)threadIdx.x < nb ? (int)threadIdx.x : 0), mine);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) shpl[threadIdx.x][e] = mine[e];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < RS_BATCH; q++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) pl[q][e] = shpl[q][e];
-                block_count_batch(pts, n, pl, nb, depth_abs, shb, cnt);     // its two barriers order these reads before the next batch's writes
-#pragma unroll
-                for (int q = 0; q < RS_BATCH; q++)
-                    if (q < nb && cnt[q] >= maximum) { a = pl[q][0]; b = pl[q][1]; c = pl[q][2]; d = pl[q][3]; maximum = cnt[q]; }
-                k += nb;
+        if (phase > 0) {
+            int best_cnt;
+            const int ix = replay_phase(cnt_all + (size_t)slot * RS_PHASE, st.maximum, sh, sh2, &best_cnt);
+            if (ix >= 0) {
+                ransac_hypothesis(pts, n, rg, (phase - 1) * RS_PHASE + ix, k0, k1, flags, st.pl);
+                st.maximum = best_cnt;
             }
         }
-        for (int round = 0; round < 1000; round++) {                        // local perturbation, main.cpp:1667-1711
-            int scn = 0;
-            for (int j = 2000; j >= 2; j /= 10, scn++) {
-                uint32_t r[4];
-                philox_raw((uint32_t)(round * 4 + scn), 0x52414E54u, (uint32_t)rg, k0, k1, r);
-                const int med = j / 2;
-                const double da = (double)((int)rnd_index(r[0], (uint32_t)j) - med) / 10000;
-                const double db = (double)((int)rnd_index(r[1], (uint32_t)j) - med) / 10000;
-                const double dc = (double)((int)rnd_index(r[2], (uint32_t)j) - med) / 10000;
-                const double dd = (double)((int)rnd_index(r[3], (uint32_t)j) - med) / 1000;
-                double ra = a + da, rb = b + db, rc = c + dc, rd = d + dd;
-                const double sq = sqrt(ra * ra + rb * rb + rc * rc);
-                ra /= sq; rb /= sq; rc /= sq; rd /= sq;
-                const int cnt = block_count(pts, n, ra, rb, rc, rd, depth_abs, sh);
-                if (cnt >= maximum) { a = ra; b = rb; c = rc; d = rd; maximum = cnt; }
+        if (phase < 10) {
+            double pl[4];
+            ransac_hypothesis(pts, n, rg, phase * RS_PHASE, k0, k1, flags, pl);
+            double depth_abs = st.depth_abs_f;
+            const int cnt = block_count<RS_BLOCK>(pts, n, pl[0], pl[1], pl[2], pl[3], depth_abs, sh);
+            if (cnt >= st.maximum) { st.pl[0] = pl[0]; st.pl[1] = pl[1]; st.pl[2] = pl[2]; st.pl[3] = pl[3]; st.maximum = cnt; }
+            // adaptive inlier threshold, main.cpp:1642-1661
+            const double rat = (double)st.maximum / (double)n;
+            if (rat < 0.3 && depth_abs < 0.003) {
+                st.depth_abs_f = (float)((double)st.depth_abs_f + 0.0001);
+            } else {
+                const int max2 = block_count<RS_BLOCK>(pts, n, st.pl[0], st.pl[1], st.pl[2], st.pl[3], (double)st.depth_abs_f + 0.0001, sh);
+                if ((double)max2 > (double)st.maximum + (double)n * 0.02) {
+                    st.depth_abs_f = (float)((double)st.depth_abs_f + 0.0001);
+                    st.maximum = max2;
+                }
             }
         }
     }
+    if (threadIdx.x == 0) state[slot] = st;
+}
+
+// inlier counts of hypotheses 1000 j + 1 + 8 b .. + 8 at the phase's threshold: grid (125, slots), 256 threads
+__global__ __launch_bounds__(RS_COUNT_BLOCK) void ransac_count_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
+                                                                      const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
+                                                                      uint32_t k0, uint32_t k1, uint32_t flags, const RansacState* __restrict__ state,
+                                                                      int* __restrict__ cnt_all, int phase) {
+    __shared__ int shb[RS_COUNT_BLOCK / 64][RS_BATCH];
+    __shared__ double shpl[RS_BATCH][4];
+    const int slot = blockIdx.y;
+    const int n = pts_count[slot];
+    if (n <= 0) return;
+    const int rg = region_of_slot[slot];
+    const float* __restrict__ pts = pts_all + 3 * (size_t)pts_start[slot];
+    const int i0 = 1 + RS_BATCH * (int)blockIdx.x;                     // index within the phase, 1..999
+    const int nb = min(RS_BATCH, RS_PHASE - i0);
+    // one thread per hypothesis builds its plane (three dependent point loads, a double sqrt and four divisions)
+    if (threadIdx.x < RS_BATCH) {
+        double mine[4];
+        ransac_hypothesis(pts, n, rg, phase * RS_PHASE + i0 + ((int)threadIdx.x < nb ? (int)threadIdx.x : 0), k0, k1, flags, mine);
+#pragma unroll
+        for (int e = 0; e < 4; e++) shpl[threadIdx.x][e] = mine[e];
+    }
+    __syncthreads();
+    int cnt[RS_BATCH];
+    block_count_batch<RS_COUNT_BLOCK, RS_BATCH>(pts, n, shpl, (double)state[slot].depth_abs_f, shb, cnt);
+    if (threadIdx.x < nb) {
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < RS_BATCH; q++) mine = ((int)threadIdx.x == q) ? cnt[q] : mine;
+        cnt_all[(size_t)slot * RS_PHASE + i0 + threadIdx.x] = mine;
+    }
+}
+
+// perturbed plane of step t (round t / 4, scale t % 4) around `base`, main.cpp:1667-1700
+DEVFN void ransac_perturb(const double* base, int t, int rg, uint32_t k0, uint32_t k1, double* out) {
+    uint32_t r[4];
+    philox_raw((uint32_t)t, 0x52414E54u, (uint32_t)rg, k0, k1, r);
+    const int scn = t & 3;
+    const int j = scn == 0 ? 2000 : (scn == 1 ? 200 : (scn == 2 ? 20 : 2));
+    const int med = j / 2;
+    const double da = (double)((int)rnd_index(r[0], (uint32_t)j) - med) / 10000;
+    const double db = (double)((int)rnd_index(r[1], (uint32_t)j) - med) / 10000;
+    const double dc = (double)((int)rnd_index(r[2], (uint32_t)j) - med) / 10000;
+    const double dd = (double)((int)rnd_index(r[3], (uint32_t)j) - med) / 1000;
+    double ra = base[0] + da, rb = base[1] + db, rc = base[2] + dc, rd = base[3] + dd;
+    const double sq = sqrt(ra * ra + rb * rb + rc * rc);
+    out[0] = ra / sq; out[1] = rb / sq; out[2] = rc / sq; out[3] = rd / sq;
+}
+
+// Stage 2 with a lookahead of G steps.  Candidate node q (1-based heap index, level g = floor(log2 q)) is the plane tried at
+// step t0 + g if the decisions of steps t0 .. t0 + g - 1 were the bits of q below its leading one (1 = accepted), read from
+// the most significant down.  Node q perturbs the base of its history: the candidate of its nearest ancestor-by-accept, or the
+// current best plane if the history holds no accept.
+template <int G>
+__global__ __launch_bounds__(RS_BLOCK) void ransac_refine_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
+                                                                 const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
+                                                                 uint32_t k0, uint32_t k1, uint32_t flags, const RansacState* __restrict__ state,
+                                                                 const int* __restrict__ cnt_all, float4* __restrict__ region_n4,
+                                                                 float* __restrict__ inlier_ratio) {
+    constexpr int NODES = (1 << G) - 1;
+    __shared__ int sh[RS_BLOCK / 64], sh2[RS_BLOCK / 64];
+    __shared__ int shb[RS_BLOCK / 64][NODES];
+    __shared__ double shpl[NODES][4];
+    const int slot = blockIdx.x;
+    const int rg = region_of_slot[slot];
+    const int n = pts_count[slot];
+    const float* __restrict__ pts = pts_all + 3 * (size_t)pts_start[slot];
+    RansacState st = state[slot];
+    if (n > 0) {
+        {   // the last phase of stage 1 still has to be replayed
+            int best_cnt;
+            const int ix = replay_phase(cnt_all + (size_t)slot * RS_PHASE, st.maximum, sh, sh2, &best_cnt);
+            if (ix >= 0) {
+                ransac_hypothesis(pts, n, rg, 9 * RS_PHASE + ix, k0, k1, flags, st.pl);
+                st.maximum = best_cnt;
+            }
+        }
+        const double depth_abs = st.depth_abs_f;
+        for (int t0 = 0; t0 < 4000; t0 += G) {
+            const int g_here = min(G, 4000 - t0);
+            // thread q-1 builds node q by walking its history from the root: at most G perturbations in a row
+            if (threadIdx.x < NODES) {
+                const int q = (int)threadIdx.x + 1;
+                const int level = 31 - __clz(q);
+                double base[4] = {st.pl[0], st.pl[1], st.pl[2], st.pl[3]};
+                double cand[4];
+                for (int g = 0; g <= level; g++) {
+                    ransac_perturb(base, t0 + g, rg, k0, k1, cand);
+                    if (g < level && ((q >> (level - 1 - g)) & 1)) { base[0] = cand[0]; base[1] = cand[1]; base[2] = cand[2]; base[3] = cand[3]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) shpl[q - 1][e] = cand[e];
+            }
+            __syncthreads();
+            int cnt[NODES];
+            block_count_batch<RS_BLOCK, NODES>(pts, n, shpl, depth_abs, shb, cnt);
+            // replay the G decisions in order (every thread, identically)
+            int q = 1;
+            for (int g = 0; g < g_here; g++) {
+                int c = 0;
+#pragma unroll
+                for (int m = 0; m < NODES; m++) c = (m == q - 1) ? cnt[m] : c;
+                const bool acc = c >= st.maximum;
+                if (acc) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) st.pl[e] = shpl[q - 1][e];
+                    st.maximum = c;
+                }
+                q = 2 * q + (acc ? 1 : 0);
+            }
+            __syncthreads();               // shpl is rewritten by the next group
+        }
+    }
     if (threadIdx.x == 0) {
-        region_n4[rg] = make_float4((float)a, (float)b, (float)c, (float)d);
-        inlier_ratio[rg] = n > 0 ? (float)maximum / (float)n : 0.f;
+        region_n4[rg] = make_float4((float)st.pl[0], (float)st.pl[1], (float)st.pl[2], (float)st.pl[3]);
+        inlier_ratio[rg] = n > 0 ? (float)st.maximum / (float)n : 0.f;
     }
 }
 
@@ -311,10 +449,21 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
             hipMemcpyAsync(d_pts_start, pts_start.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
         }
         hipMemcpyAsync(d_pts_count, pts_count.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+        RansacState* d_state = (RansacState*)dmalloc((size_t)nslot * sizeof(RansacState));
+        int* d_cnt = (int*)dmalloc((size_t)nslot * RS_PHASE * sizeof(int));
+        if (!d_state || !d_cnt) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+        static const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 2;
         {
             ScopedKernelTimer tm(ctx, "ransac_fit");
-            hipLaunchKernelGGL(ransac_fit_kernel, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->region_size,
-                               ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, ctx->region_n4, d_ratio);
+            for (int phase = 0; phase < 10; phase++) {
+                hipLaunchKernelGGL(ransac_adapt_kernel, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->region_size,
+                                   ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, phase);
+                hipLaunchKernelGGL(ransac_count_kernel, dim3(RS_BATCHES, nslot), dim3(RS_COUNT_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot,
+                                   ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, phase);
+            }
+            auto refine = lookahead == 1 ? ransac_refine_kernel<1> : (lookahead == 3 ? ransac_refine_kernel<3> : ransac_refine_kernel<2>);
+            hipLaunchKernelGGL(refine, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->hscene.seed_lo,
+                               ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio);
         }
         if (hipGetLastError() != hipSuccess) return done(TSAR_ERR_HIP, "ransac launch failed");
     }
