@@ -446,7 +446,11 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     m.close()
 
 
-def test_ransac_regions_bit_exact(mid_scene):
+@pytest.mark.parametrize("lookahead", ["1", "2", "3"])
+def test_ransac_regions_bit_exact(mid_scene, monkeypatch, lookahead):
+    """lookahead: how many perturbation steps of stage 2 share one pass over the points (ransac_kernels.hip); every setting
+    must replay the reference's sequential accept order exactly"""
+    monkeypatch.setenv("TSAR_RANSAC_LOOKAHEAD", lookahead)
     sc = mid_scene
     h, w = sc.h, sc.w
     orc, m = _prepared_pair(sc, 12)

@@ -82,10 +82,9 @@ DEVFN uint32_t rnd_index(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)
 //            sequential accept rule on the stored counts — `cnt >= maximum` in index order picks the LAST hypothesis that
 //            attains the phase's maximum count — and performs the adaptation step (hypothesis 1000 j, the `max2` re-count).
 //   stage 2: 1 000 rounds x 4 perturbation scales, each perturbing the current best plane: truly sequential, one
-//            workgroup per region.  ransac_refine_kernel looks G steps ahead: the 2^G - 1 candidate planes of every
-//            accept / reject history of the next G steps are counted in ONE pass over the points (the pass, not the
-//            arithmetic, is what a step costs: 600 KB of points stream from L2 each time), then the G decisions are
-//            replayed in order on the counts.  Same planes, same counts, same decisions as the sequential loop.
+//            workgroup per region.  ransac_refine_kernel can look G steps ahead: the 2^G - 1 candidate planes of every
+//            accept / reject history of the next G steps are counted in ONE pass over the points, then the G decisions are
+//            replayed in order on the counts.  Same planes, same counts, same decisions as the sequential loop (G = 1).
 // State between kernels lives in RansacState (one per region slot); counts in cnt[slot][1000].
 struct RansacState {
     double pl[4];          // best plane so far (a, b, c, d)
@@ -452,7 +451,10 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         RansacState* d_state = (RansacState*)dmalloc((size_t)nslot * sizeof(RansacState));
         int* d_cnt = (int*)dmalloc((size_t)nslot * RS_PHASE * sizeof(int));
         if (!d_state || !d_cnt) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
-        static const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 2;
+        // measured on six ~50 000-point regions: lookahead 1 / 2 / 3 -> 25.9 / 26.4 / 33.7 ms: the passes are bound by the CU's FP64
+        // rate (7 operations per point and plane), not by streaming the points, so the extra planes of a lookahead cost what
+        // the saved passes return.  1 is the default; 2 and 3 stay selectable (and tested) for other region sizes.
+        const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 1;
         {
             ScopedKernelTimer tm(ctx, "ransac_fit");
             for (int phase = 0; phase < 10; phase++) {
