@@ -249,6 +249,16 @@ int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, co
 void* tsar_host_alloc(size_t bytes);
 void tsar_host_free(void* p);
 
+/* ---- device buffers for a multi-GPU host -------------------------------------------------------- */
+/* Plain device memory on `device` (NULL on failure) and a synchronous device-to-device copy between two devices of the node
+ * (xGMI peer copy; also valid with dst_device == src_device).  tsar_gipuma --all --fuse keeps each view's result on the GPU
+ * that matched it and gathers them to the fusing GPU with these, where the reference's pipeline goes through files
+ * (scripts/courtyard.sh:29-48, x/1.sh:30). */
+void* tsar_device_alloc(int device, size_t bytes);
+void tsar_device_free(int device, void* p);
+int tsar_device_write(int device, void* dst, const void* host_src, size_t bytes);     /* synchronous host -> device copy */
+int tsar_peer_copy(int dst_device, void* dst, int src_device, const void* src, size_t bytes);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the context's stream. */
 int tsar_enable_kernel_timing(tsar_ctx* ctx, int enable);

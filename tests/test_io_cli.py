@@ -120,6 +120,26 @@ def test_fusion_cli_reads_what_the_matcher_cli_writes(tmp_path):
     assert np.isfinite(rec["p"]).all() and np.allclose(np.linalg.norm(rec["n"], axis=1), 1, atol=1e-4)
 
 
+@pytest.mark.gpu
+def test_all_fuse_in_one_process_equals_the_two_stage_pipeline(tmp_path):
+    """tsar_gipuma --all --fuse keeps every view's maps on the GPU, gathers them to the fusing GPU (tsar_peer_copy; with one
+    GPU the copies are device-local) and fuses there: the cloud must be byte-identical to what the file-based second stage
+    (tsar_fusion on the .dmb files of the same run) writes"""
+    sc = synth.make_scene(160, 120, 3, seed=6)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    out = subprocess.run([CLI, "--all", "--gpus=1", "--workers=2", "--fuse", "--num_consistent=2", "-mslp_folder", root, "-images_folder", root + "images/",
+                          "--iterations=3", "--blocksize=11", "--n_best=1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fused 4 views on gpu 0" in out.stdout
+    in_process = open(root + "APD/APD_TSAR.ply", "rb").read()
+    os.remove(root + "APD/APD_TSAR.ply")
+    out = subprocess.run([FUSION, root, "--num_consistent=", "2"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert open(root + "APD/APD_TSAR.ply", "rb").read() == in_process
+    assert len(in_process) > 27 * 1000
+
+
 def test_weak_png_mask_decoding(tmp_path):
     """weak.png of the reference's live path (main.cpp:1499-1514): white / pure green / pure red pixels are
     reliable.  The C++ reader (host/tsar_io.h, zlib) must undo every PNG row filter."""

@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
     "tsar_set_reliable_mask", "tsar_get_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse",
-    "tsar_host_alloc", "tsar_host_free", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
+    "tsar_host_alloc", "tsar_host_free", "tsar_device_alloc", "tsar_device_free", "tsar_device_write", "tsar_peer_copy", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
 ]
 
 _lib = None
@@ -110,6 +110,12 @@ def load_library(path: str = LIB_PATH):
     L.tsar_host_alloc.argtypes = [C.c_size_t]
     L.tsar_host_free.restype = None
     L.tsar_host_free.argtypes = [C.c_void_p]
+    L.tsar_device_alloc.restype = C.c_void_p
+    L.tsar_device_alloc.argtypes = [C.c_int, C.c_size_t]
+    L.tsar_device_free.restype = None
+    L.tsar_device_free.argtypes = [C.c_int, C.c_void_p]
+    L.tsar_device_write.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tsar_peer_copy.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.tsar_lrdiff.argtypes = [C.c_void_p]
     L.tsar_getview.argtypes = [C.c_void_p]
     L.tsar_wmf.argtypes = [C.c_void_p, C.c_int, C.c_int]

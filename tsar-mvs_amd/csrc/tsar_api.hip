@@ -705,6 +705,40 @@ extern "C" void tsar_host_free(void* p) {
     if (p) hipHostFree(p);
 }
 
+// ---- device buffers for a multi-GPU host (tsar_gipuma --all --fuse) -----------------------------------------
+// One host process drives every GPU of the node (one worker thread + context per device).  Results that are to be fused
+// stay on the device that produced them and travel to the fusing device directly over xGMI (peer copy) — the role the
+// file system plays in the reference's per-view shell loop (scripts/courtyard.sh:29-48 -> Fusion.exe).  Inside one process
+// a peer copy IS the point-to-point transfer a gather is made of; RCCL carries the same gather between the one-rank-per-GPU
+// processes of bench.py (driver.gather_results).
+extern "C" void* tsar_device_alloc(int device, size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void tsar_device_free(int device, void* p) {
+    if (p && hipSetDevice(device) == hipSuccess) hipFree(p);
+}
+extern "C" int tsar_device_write(int device, void* dst, const void* host_src, size_t bytes) {
+    if (!dst || !host_src) return TSAR_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess || hipMemcpy(dst, host_src, bytes, hipMemcpyHostToDevice) != hipSuccess) return TSAR_ERR_HIP;
+    return TSAR_OK;
+}
+extern "C" int tsar_peer_copy(int dst_device, void* dst, int src_device, const void* src, size_t bytes) {
+    if (!dst || !src) return TSAR_ERR_INVALID;
+    if (hipSetDevice(dst_device) != hipSuccess) return TSAR_ERR_HIP;
+    if (dst_device != src_device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst_device, src_device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return TSAR_ERR_HIP;
+            (void)hipGetLastError();
+        }
+    }
+    if (hipMemcpyPeer(dst, dst_device, src, src_device, bytes) != hipSuccess) return TSAR_ERR_HIP;   // synchronous: complete on return
+    return TSAR_OK;
+}
+
 // ---- measurement ---------------------------------------------------------------------------------
 extern "C" int tsar_enable_kernel_timing(tsar_ctx* ctx, int enable) {
     if (!ctx) return TSAR_ERR_INVALID;

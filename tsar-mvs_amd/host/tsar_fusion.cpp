@@ -8,23 +8,6 @@
 
 #include "tsar_io.h"
 
-static bool write_ply(const std::string& path, const float* pts, int64_t n) {
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) return false;
-    fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\n"
-               "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", (long long)n);
-    for (int64_t i = 0; i < n; i++) {
-        const float* p = pts + 9 * i;
-        fwrite(p, sizeof(float), 6, f);
-        float g = p[6] < 0 ? 0 : (p[6] > 255 ? 255 : p[6]);
-        const unsigned char c = (unsigned char)(g + 0.5f);
-        const unsigned char rgb[3] = {c, c, c};
-        fwrite(rgb, 1, 3, f);
-    }
-    fclose(f);
-    return true;
-}
-
 int main(int argc, char** argv) {
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
         printf("usage: tsar_fusion <mslp_dir> [--num_consistent= N] [--reproj_error= PX] [--depth_diff= REL] [--angle= DEG] [--used_list= 0|1] [--gpu=K]\n");
@@ -93,7 +76,7 @@ int main(int argc, char** argv) {
     if (rc != TSAR_OK) { fprintf(stderr, "tsar_fuse failed: %d\n", rc); return 1; }
     if (cnt > cap) cnt = cap;
     const std::string out = dir + "APD/APD_TSAR.ply";
-    if (!write_ply(out, pts.data(), cnt)) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+    if (!write_cloud_ply(out, pts.data(), cnt)) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
     printf("%lld points -> %s\n", (long long)cnt, out.c_str());
     return 0;
 }

@@ -13,6 +13,10 @@
 //   --mode=tsar is the reference's live path (external planes + weak.png -> region RANSAC -> plane fill);
 //   --mode=patchmatch  (default) random init + iterations; --mode=load starts from
 //                      APD/<id>/depths_geom.dmb + normals.dmb like the reference snapshot (main.cpp:1462-1490)
+//   --all --fuse       after matching, every view's depth / normal map is gathered from the GPU that produced it to GPU 0
+//                      over xGMI (tsar_peer_copy) and fused there (tsar_fuse) into D/APD/APD_TSAR.ply — the fuser of
+//                      x/1.sh:30 without the round trip through .dmb files (which are still written)
+//   --num_consistent= --reproj_error= --depth_diff= --angle= --used_list=   the fuser's options (x/1.sh:20-30), for --fuse
 //   --seed=S, --strict, --fix-quirks
 // Images: binary PGM (the image has no JPEG decoder; `python -m tsar_mvs_amd.io convert a.jpg a.pgm`).
 // A name ending in .jpg/.png is looked up as the same stem + .pgm.
@@ -40,7 +44,8 @@ struct Options {
     std::string images_folder, mslp_folder, krt_file, output_folder;
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
-    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false;
+    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false;
+    tsar_fusion_params fusion{};
     int gpus = 1, workers = 2;      // --all: worker threads per GPU (file I/O of one view overlaps the kernels of another)
     uint64_t seed = 0;
     std::string mode = "patchmatch";
@@ -66,7 +71,8 @@ static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
            "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [-color_processing] [--display_outputs]\n"
-           "       tsar_gipuma --all [--gpus=N] -images_folder DIR/ -mslp_folder DIR/ [options]\n");
+           "       tsar_gipuma --all [--gpus=N] [--fuse [--num_consistent=N --reproj_error=PX --depth_diff=REL --angle=DEG --used_list=0|1]]\n"
+           "                   -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
 
 static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946: same spellings, unknown options only warn
@@ -105,6 +111,12 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
             return 1;
         }
         else if (!strcmp(a, "--all")) o.all = true;
+        else if (!strcmp(a, "--fuse")) o.fuse = true;
+        else if (starts("--num_consistent=")) o.fusion.num_consistent = atoi(a + 17);
+        else if (starts("--reproj_error=")) o.fusion.reproj_error = (float)atof(a + 15);
+        else if (starts("--depth_diff=")) o.fusion.depth_diff = (float)atof(a + 13);
+        else if (starts("--angle=")) o.fusion.angle_deg = (float)atof(a + 8);
+        else if (starts("--used_list=")) o.fusion.used_list = atoi(a + 12);
         else if (!strcmp(a, "--strict")) o.strict = true;
         else if (!strcmp(a, "--fix-quirks")) o.fix_quirks = true;
         else if (!strcmp(a, "-images_folder") && i + 1 < argc) o.images_folder = argv[++i];
@@ -143,8 +155,16 @@ struct ImageCache {
 };
 static ImageCache g_images;
 
+// --fuse: what a matched view leaves on its GPU for the gather (device memory, owned by the run)
+struct DeviceResult {
+    int device = -1, w = 0, h = 0;
+    float *depth = nullptr, *normal = nullptr;
+    tsar_camera cam{};
+};
+
 // one reference view: images[0] is the reference, the rest the candidate sources in argv order
-static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds) {
+static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds,
+                    DeviceResult* keep = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
     const int n = (int)names.size();
     std::vector<std::shared_ptr<ImageCache::Entry>> gray(n);
@@ -219,6 +239,13 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     } else if (tsar_compute_disp(ctx) != TSAR_OK) return fail("tsar_compute_disp");
     std::vector<float> depth(np), normal(3 * np);
     if (tsar_get_result(ctx, depth.data(), normal.data(), nullptr, nullptr, TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_get_result");
+    if (keep) {   // the same maps stay on this GPU for the gather to the fusing device
+        keep->device = device; keep->w = w; keep->h = h; keep->cam = cams[0];
+        keep->depth = (float*)tsar_device_alloc(device, np * 4);
+        keep->normal = (float*)tsar_device_alloc(device, np * 12);
+        if (!keep->depth || !keep->normal) return fail("tsar_device_alloc");
+        if (tsar_get_result(ctx, keep->depth, keep->normal, nullptr, nullptr, TSAR_MEM_DEVICE) != TSAR_OK) return fail("tsar_get_result (device)");
+    }
     tsar_destroy(ctx);
     if (!write_dmb(out_dir + "TSAR_disp.dmb", depth.data(), h, w, 1)) return -1;
     if (!write_dmb(out_dir + "TSAR_normals.dmb", normal.data(), h, w, 3)) return -1;
@@ -240,6 +267,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
 
 int main(int argc, char** argv) {
     Options o;
+    tsar_default_fusion_params(&o.fusion);
     const int pr = parse_args(argc, argv, o);
     if (pr != 0) return pr < 0 ? 1 : 0;
     if (o.mslp_folder.empty() || o.images_folder.empty()) { usage(); return 1; }
@@ -254,6 +282,7 @@ int main(int argc, char** argv) {
         const int ngpu = o.gpus < 1 ? 1 : o.gpus;
         const int nthr = ngpu * (o.workers < 1 ? 1 : o.workers);   // worker t drives GPU t % ngpu with its own context
         std::vector<int> status(nthr, 0);
+        std::vector<DeviceResult> kept(o.fuse ? refs.size() : 0);
         std::vector<std::thread> th;
         for (int t = 0; t < nthr; t++)
             th.emplace_back([&, t]() {
@@ -266,7 +295,7 @@ int main(int argc, char** argv) {
                     names.push_back(buf);
                     for (int s : pairs[ref]) { snprintf(buf, sizeof buf, "%08d.pgm", s); names.push_back(buf); }
                     double sec = 0;
-                    const int rc = run_view(o, g, names, {}, ref, &sec);
+                    const int rc = run_view(o, g, names, {}, ref, &sec, o.fuse ? &kept[k] : nullptr);
                     printf("view %08d on gpu %d: %s (%.2f s)\n", ref, g, rc == 0 ? "ok" : "FAILED", sec);
                     if (rc != 0) status[t] = rc;   // a failed view does not stop the others
                 }
@@ -274,6 +303,69 @@ int main(int argc, char** argv) {
         for (auto& t : th) t.join();
         for (int s : status)
             if (s != 0) return 1;
+        if (o.fuse) {
+            // gather: every view's maps to GPU 0 (peer copies over xGMI; views matched on GPU 0 are already there), then fuse
+            const auto t0 = std::chrono::steady_clock::now();
+            const int n = (int)refs.size(), fw = kept[0].w, fh = kept[0].h;
+            const size_t np = (size_t)fw * fh;
+            std::map<int, int> slot;
+            for (int k = 0; k < n; k++) slot[refs[k]] = k;
+            std::vector<const float*> pd(n), pn(n), pg(n);
+            std::vector<tsar_camera> cams(n);
+            std::vector<void*> owned;                       // device-0 buffers to release
+            auto release = [&]() { for (void* q : owned) tsar_device_free(0, q); };
+            size_t moved = 0;
+            for (int k = 0; k < n; k++) {
+                if (kept[k].w != fw || kept[k].h != fh) { fprintf(stderr, "--fuse: views differ in size\n"); release(); return 1; }
+                float *d = kept[k].depth, *nr = kept[k].normal;
+                if (kept[k].device != 0) {
+                    float* d0 = (float*)tsar_device_alloc(0, np * 4);
+                    float* n0 = (float*)tsar_device_alloc(0, np * 12);
+                    if (!d0 || !n0 || tsar_peer_copy(0, d0, kept[k].device, d, np * 4) != TSAR_OK || tsar_peer_copy(0, n0, kept[k].device, nr, np * 12) != TSAR_OK) {
+                        fprintf(stderr, "--fuse: gather of view %08d from gpu %d failed\n", refs[k], kept[k].device);
+                        release();
+                        return 1;
+                    }
+                    tsar_device_free(kept[k].device, d);
+                    tsar_device_free(kept[k].device, nr);
+                    d = d0; nr = n0;
+                    moved += np * 16;
+                }
+                owned.push_back(d); owned.push_back(nr);
+                char buf[32];
+                snprintf(buf, sizeof buf, "%08d.pgm", refs[k]);
+                auto img = g_images.get(o.images_folder + pnm_name(buf, o.color ? ".ppm" : ".pgm"));
+                float* g0 = (float*)tsar_device_alloc(0, np * 4);
+                if (g0) owned.push_back(g0);
+                if (!img->ok || !g0 || tsar_device_write(0, g0, img->gray.data(), np * 4) != TSAR_OK) { fprintf(stderr, "--fuse: image of view %08d\n", refs[k]); release(); return 1; }
+                pd[k] = d; pn[k] = nr; pg[k] = g0;
+                char cname[32];
+                snprintf(cname, sizeof cname, "%08d", refs[k]);
+                CamFile cf;
+                if (!read_cam(o.mslp_folder + "cams/" + cname + "_cam.txt", cf)) { fprintf(stderr, "--fuse: camera of view %08d\n", refs[k]); release(); return 1; }
+                cams[k] = cf.cam;
+            }
+            const double t_gather = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::vector<int32_t> off(n + 1, 0), idx;
+            for (int k = 0; k < n; k++) {
+                for (int sv : pairs[refs[k]])
+                    if (slot.count(sv)) idx.push_back(slot[sv]);
+                off[k + 1] = (int32_t)idx.size();
+            }
+            if (idx.empty()) idx.push_back(0);
+            const int64_t cap = (int64_t)n * fw * fh;
+            std::vector<float> pts((size_t)cap * 9);
+            int64_t cnt = 0;
+            const int rc = tsar_fuse(0, n, fw, fh, cams.data(), pd.data(), pn.data(), pg.data(), TSAR_MEM_DEVICE, off.data(), idx.data(), &o.fusion, pts.data(), cap, &cnt);
+            release();
+            if (rc != TSAR_OK) { fprintf(stderr, "tsar_fuse failed: %d\n", rc); return 1; }
+            if (cnt > cap) cnt = cap;
+            const std::string out = o.mslp_folder + "APD/APD_TSAR.ply";
+            if (!write_cloud_ply(out, pts.data(), cnt)) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+            const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("fused %d views on gpu 0: %lld points -> %s (gather of %.1f MB from other gpus + uploads %.3f s, total %.3f s)\n", n, (long long)cnt, out.c_str(),
+                   moved / 1e6, t_gather, t_all);
+        }
         return 0;
     }
     if (o.images.size() < 2) { usage(); return 1; }

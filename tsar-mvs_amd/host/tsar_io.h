@@ -268,3 +268,22 @@ static inline bool read_reliable_mask(const std::string& path, std::vector<float
     }
     return true;
 }
+
+// fused cloud, binary little-endian: x y z nx ny nz red green blue per point (records of 9 floats from tsar_fuse)
+static bool write_cloud_ply(const std::string& path, const float* pts, int64_t n) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\n"
+               "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", (long long)n);
+    for (int64_t i = 0; i < n; i++) {
+        const float* p = pts + 9 * i;
+        fwrite(p, sizeof(float), 6, f);
+        float g = p[6] < 0 ? 0 : (p[6] > 255 ? 255 : p[6]);
+        const unsigned char c = (unsigned char)(g + 0.5f);
+        const unsigned char rgb[3] = {c, c, c};
+        fwrite(rgb, 1, 3, f);
+    }
+    fclose(f);
+    return true;
+}
+
