@@ -128,6 +128,33 @@ def test_cfg2_full_size_properties():
     m.close()
 
 
+@pytest.mark.parametrize("block", ["128", "256"])
+@pytest.mark.parametrize("w,h", [(192, 128), (101, 67)])
+def test_both_workgroup_shapes_bit_exact(monkeypatch, block, w, h):
+    """the sweep runs as 256-thread (32 x 16 pixel) workgroups, or 128-thread (32 x 8) ones on small images; small test scenes
+    would only ever see the latter, so both shapes are forced here (TSAR_BLOCK is read at every launch)"""
+    monkeypatch.setenv("TSAR_BLOCK", block)
+    sc = synth.make_scene(w, h, 4, seed=31)
+    orc = _oracle(sc, seed=23)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    m = api.matcher_from_scene(sc, seed=23, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(2)
+    _assert_state_equal(m, orc)
+    m.close()
+    f = api.matcher_from_scene(sc, seed=23)                 # fast mode: same decisions up to near-ties
+    f.set_plane(orc.norm4.copy(), orc.c.copy())
+    f.set_sweep_counter(4)
+    orc.pm_sweep(0)
+    f.pm_sweep(0)
+    planes, cost, _, _ = f.get_plane()
+    f.close()
+    same = np.all(planes.view(np.uint32) == orc.norm4.view(np.uint32), axis=-1)
+    assert same.mean() > 0.85
+    assert np.max(np.abs(cost - orc.c)[same]) <= 1e-3
+
+
 @pytest.mark.parametrize("variant", ["114"])
 def test_tap_loop_without_d16_loads_bit_exact(monkeypatch, variant):
     """the tap-loop variant tsar_create falls back to when the D16 probe fails (no ds_read_u16_d16_hi): forced here"""

@@ -42,21 +42,24 @@ for v in variants:
     for k in env:
         os.environ.pop(k)
     m.enable_kernel_timing(True)
-    ms[v] = (m, [], [])
+    ms[v] = (m, [], [], env)
 os.environ.pop("TSAR_VARIANT", None)
 for r in range(args.rounds + 1):
     for v in variants:
-        m, sweep, init = ms[v]
+        m, sweep, init, env = ms[v]
+        os.environ.update(env)                      # knobs read per launch (TSAR_BLOCK) as well as per context
         m.reset_kernel_timing()
         m.pm_init()
         m.pm_iterate(args.iters)
         t = m.kernel_timing()
+        for k in env:
+            os.environ.pop(k)
         if r > 0:                                   # round 0 warms up
             sweep.append(t["pm_sweep"][1] / t["pm_sweep"][0])
             init.append(t["pm_init"][1] / t["pm_init"][0])
 out = {}
 for v in variants:
-    m, sweep, init = ms[v]
+    m, sweep, init, env = ms[v]
     m.compute_disp()
     d = torch.empty((args.height, args.width), dtype=torch.float32, device="cuda")
     m.get_result_device(depth=d)

@@ -83,12 +83,12 @@ __host__ __device__ constexpr size_t tile_bytes(int tw, int th) {
     return ((size_t)tw * th * sizeof(typename TileOf<QUAD>::type) + 15) & ~(size_t)15;
 }
 
-template <int RH, typename TileT>
+template <int RH, typename TileT, int BLK = PM_BLOCK>
 DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, TileT* tile, int x0, int y0, int hr, int vr) {
     const int tw = PM_RW + 2 * hr, th = RH + 2 * vr;
     const global_f32_ptr img = (global_f32_ptr)sc->view[0].img;
     const int w = sc->w, h = sc->h;
-    for (int k = threadIdx.x; k < tw * th; k += PM_BLOCK) {
+    for (int k = threadIdx.x; k < tw * th; k += BLK) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = min(max(x0 + tx - hr, 0), w - 1), gy = min(max(y0 + ty - vr, 0), h - 1);
         tile_store(&tile[k], img[(size_t)gy * w + gx]);
@@ -97,7 +97,7 @@ DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, TileT* tile, int x0, 
 
 // Bilateral weights + reference moments (gipuma.cu:247-277, the parts that depend on the reference
 // image only).  own = index of this thread's pixel in the tile, wts = LDS weight column of this thread.
-template <int HR, typename TileT>
+template <int HR, typename TileT, int BLK = PM_BLOCK>
 DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, int hr_rt, int vr_rt) {
     const int hr = HR > 0 ? HR : hr_rt, vr = HR > 0 ? HR : vr_rt;
     const float cen = tile_value(tile[own]);
@@ -111,7 +111,7 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
             const float sd = sqrtf((float)(i * i + j * j));
             const float cd = fabsf(r - cen);
             const float wt = tsar_expf(-sd / 50.0f - cd / 18.0f);   // sigma_spatial 5, sigma_color 3 (gipuma.cu:248-249,268)
-            wts[tap * PM_BLOCK] = wt;
+            wts[tap * BLK] = wt;
             const float wr = wt * r;
             sum_ref += wr;
             sum_ref_ref = fma_(wr, r, sum_ref_ref);
@@ -144,7 +144,8 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          loads, right before issuing the gathers), the tap's byte offset is a plain shift, and the column's six
 //          bilateral weights are loaded at the top of the column with its reference texels instead of one LDS round trip
 //          per pair of taps inside the blend phase
-template <int HR, bool STRICT, bool QUAD, int V = 0>
+// BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread])
+template <int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
                       const PixelRef& pr, int x, int y, const float4& n4) {
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
@@ -194,11 +195,12 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         float rcol[6];
         f32x2 wcol[3];
         if (V & 64) {
-            // the column's six weights, [tap][thread] layout: taps are 1 KiB apart = 4 units of ds_read2st64's 256-byte stride
-            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + tap * PM_BLOCK);
+            // the column's six weights, [tap][thread] layout: taps are BLK floats apart = BLK / 64 units of ds_read2st64's 256-byte stride
+            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + tap * BLK);
+            constexpr int U = BLK / 64;
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(8 * k), "n"(8 * k + 4), "v"(bz));
+                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(2 * U * k), "n"(2 * U * k + U), "v"(bz));
         }
         if (V & 8) {
             // the column's six reference texels, each loaded into bits 31:16 of a register = its fp32 value.  gfx950 runs
@@ -296,7 +298,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             } else {
                 r = tile_value(tile[own + (2 * jj - 5) * tw + i]);
             }
-            const float wt = (V & 64) ? wcol[jj >> 1][jj & 1] : wts[(tap + jj) * PM_BLOCK];
+            const float wt = (V & 64) ? wcol[jj >> 1][jj & 1] : wts[(tap + jj) * BLK];
             const float ws = wt * s;
             sum_src += ws;
             sum_src_src = fma_(ws, s, sum_src_src);
@@ -324,7 +326,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             }
             const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
             const float r = tile_value(tile[own + j * tw + i]);
-            const float wt = wts[tap * PM_BLOCK];
+            const float wt = wts[tap * BLK];
             const float ws = wt * s;
             sum_src += ws;
             sum_src_src = fma_(ws, s, sum_src_src);
@@ -357,7 +359,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
 
 // pmCostMultiview_cu gipuma.cu:455-518: best-N combination over the selected views.  The NB
 // smallest costs are kept sorted in registers (sort_small :425-434 sorts all of them).
-template <int NB, int HR, bool STRICT, bool QUAD, int V = 0>
+template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts, const PixelRef& pr,
                            int x, int y, const float4& n4, int& beview, float& ratio) {
     float best[NB];
@@ -368,7 +370,7 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
     float cmin = __builtin_inff();
     for (int i = 0; i < num; i++) {
         const int vi = sc->sel[i];
-        float c = view_cost<HR, STRICT, QUAD, V>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        float c = view_cost<HR, STRICT, QUAD, V, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;
         if (c <= cmin) { cmin = c; bv = vi; }   // last view attaining the minimum (gipuma.cu:506-510)
         float v = c;

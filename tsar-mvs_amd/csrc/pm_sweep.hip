@@ -12,7 +12,10 @@
 // reference reads and writes the same array concurrently.
 #include "pm_core.h"
 
-#define SWEEP_RH 16  // region 32 x 16 pixels = 256 pixels of the active colour
+// Workgroup = BLK threads = a region of 32 x BLK/16 pixels, one thread per pixel of the active colour.  BLK = 256 (32 x 16) is
+// the production shape; BLK = 128 (32 x 8) is used for small images, where 256-thread tiles number fewer than the ~1000
+// workgroup slots of the chip and leave CUs idle or unevenly loaded (640 x 480: 600 tiles of 256, 1200 of 128).
+#define SWEEP_SMALL_IMAGE_TILES 3072   // below this many 256-thread tiles the 128-thread shape is launched
 
 // A candidate is the pixel index of the neighbour whose plane is tried, with bit 30 set if that neighbour has the
 // active colour (its plane is read from same_in); -1 = arm skipped.
@@ -129,8 +132,8 @@ DEVFN bool same_bits(const float4& a, const float4& b) {
            __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
 }
 
-template <int NB, int HR, bool STRICT, bool QUAD, int V = 0>
-__global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
+template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
+__global__ __launch_bounds__(BLK) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
                                                             const float* __restrict__ c_same, const float4* __restrict__ n_same,
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
                                                             const float* __restrict__ final_text) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename TileOf<QUAD>::type TileT;
+    constexpr int SWEEP_RH = BLK / 16;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int tw = PM_RW + 2 * hr, th = SWEEP_RH + 2 * vr;
     TileT* tile = (TileT*)lds_raw;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
     int tix, tiy;
     strip_tile(t, tiles_x, n_tiles / tiles_x, strip_w, tix, tiy);
     const int ty0 = tiy * SWEEP_RH, tx0 = tix * PM_RW;
-    stage_ref_tile<SWEEP_RH, TileT>(sc, tile, tx0, ty0, hr, vr);
+    stage_ref_tile<SWEEP_RH, TileT, BLK>(sc, tile, tx0, ty0, hr, vr);
     __syncthreads();
 
     const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
     // the kernels' `final == true` mode (gipuma.cu:856, :1063): pixels whose lines->text is -1 keep their state
     // (copied across the ping-pong), and no accepted hypothesis writes ratio / beview (:559-562, :669-672)
     if (final_text && final_text[p] == -1.0f) { c_out[p] = cost_now; n_out[p] = n_now; return; }
-    const PixelRef pr = hoist_reference<HR, TileT>(tile, tw, own, wts, hr, vr);
+    const PixelRef pr = hoist_reference<HR, TileT, BLK>(tile, tw, own, wts, hr, vr);
     bool wrote = false;
     float ratio_w = 0.f;
     int beview_w = 0;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
                 deltaZ = deltaZ / 10.0f;
             }
             int bv; float rt;
-            const float cost_t = multiview_cost<NB, HR, STRICT, QUAD, V>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
+            const float cost_t = multiview_cost<NB, HR, STRICT, QUAD, V, BLK>(sc, tile, tw, own, wts, pr, x, y, n_t, bv, rt);
             if (cost_t < cost_now) {
                 cost_now = cost_t; n_now = n_t; depth_now = depth_t;
                 ratio_w = rt; beview_w = bv; wrote = true;
@@ -240,19 +244,20 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_sweep_kernel(const DevScene* __re
 }
 
 
-template <int NB, int HR, bool STRICT, bool QUAD, int V = 0>
+template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                           uint32_t stream_id, int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
+    constexpr int SWEEP_RH = BLK / 16;
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
     const int n_tiles = tiles_x * tiles_y;
     static const size_t lds_pad = getenv("TSAR_LDS_PAD") ? (size_t)atoi(getenv("TSAR_LDS_PAD")) : 0;   // occupancy experiments: unused LDS per workgroup
-    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK + lds_pad;
-    auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD, V>;
+    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad) + sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * BLK + lds_pad;
+    auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD, V, BLK>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ScopedKernelTimer tm(ctx, "pm_sweep");
-        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(PM_BLOCK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
+        hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(BLK), lds, ctx->stream, ctx->dscene, colour, same_in.c, same_in.n4, other.c,
                            other.n4, same_out.c, same_out.n4, ctx->ratio, ctx->beview, stream_id, do_prop, do_refine, tiles_x, n_tiles,
                            ctx->cost_consistent ? 1 : 0, strip_width(ctx->strip_w, tiles_x), ctx->final_text);
     }
@@ -268,6 +273,13 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     // the oracle's arithmetic (IEEE divides, min/max, floor) with the same loads, clamp-free loop and priorities: same
     // bits as the generic strict kernel.
     if (quad && NB == 2 && HR == 5) {
+        // small images: 128-thread workgroups (see SWEEP_SMALL_IMAGE_TILES); TSAR_BLOCK=128|256 forces a shape (A/B runs)
+        const int tiles256 = ((ctx->hscene.w + PM_RW - 1) / PM_RW) * ((ctx->hscene.h + 15) / 16);
+        bool small = tiles256 < SWEEP_SMALL_IMAGE_TILES;
+        if (const char* e = getenv("TSAR_BLOCK")) small = atoi(e) == 128;
+        if (small && ctx->variant == 122) {
+            return strict ? launch_sweep_t<2, 5, true, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
+        }
         if (strict) {
             switch (ctx->variant) {
                 case 122: return launch_sweep_t<2, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
