@@ -144,6 +144,11 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          loads, right before issuing the gathers), the tap's byte offset is a plain shift, and the column's six
 //          bilateral weights are loaded at the top of the column with its reference texels instead of one LDS round trip
 //          per pair of taps inside the blend phase
+//   bit 7: fast mode, radius 5 — the window is walked ROW by row (six taps along x per trip) instead of column by column.  A
+//          row's six taps of one lane fall into one or two cache lines of the source texture, so in the random-plane regime
+//          (init, the first sweep: neighbouring lanes' footprints are unrelated and L2 bandwidth is the bound) the six gathers
+//          of a trip reuse the lines the first one brought into L1.  Changes the summation order of the three tap sums, hence
+//          fast mode only; strict keeps the oracle's column order.
 // BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread])
 template <int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
@@ -188,19 +193,22 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         asm volatile("" : "+s"(qb_lo), "+s"(qb_hi));
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr bool ROW = (V & 128) && !STRICT;     // bit 7: `i` below is then the row offset and the six taps run along x
     auto column_fast = [&](int i, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
-        const float xi = (float)(x + i);
-        const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
+        const float xi = (float)((ROW ? y : x) + i);
+        const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
+        const int line = (i + 5) >> 1;                // 0..5: which column (or row) this is
         float rcol[6];
         f32x2 wcol[3];
         if (V & 64) {
-            // the column's six weights, [tap][thread] layout: taps are BLK floats apart = BLK / 64 units of ds_read2st64's 256-byte stride
-            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + tap * BLK);
-            constexpr int U = BLK / 64;
+            // the line's six weights, [tap][thread] layout, tap = 6 * column + row: taps are BLK floats apart = BLK / 64 units of
+            // ds_read2st64's 256-byte stride; along a row consecutive taps are 6 taps apart
+            constexpr int U = BLK / 64, S = ROW ? 6 : 1;
+            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + (ROW ? line : 6 * line) * BLK);
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(2 * U * k), "n"(2 * U * k + U), "v"(bz));
+                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(2 * U * S * k), "n"(2 * U * S * k + U * S), "v"(bz));
         }
         if (V & 8) {
             // the column's six reference texels, each loaded into bits 31:16 of a register = its fp32 value.  gfx950 runs
@@ -210,18 +218,18 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             // conservative); the wait for these six is the asm before their first use below.  Neither asm is volatile
             // (a volatile one fences the gathers and serialises the taps); the unused bz operand keeps the loads inside
             // the column loop instead of being hoisted out of the view and hypothesis loops into 36 live registers.
-            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(tile + own + i - 5 * tw);
+            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(ROW ? tile + own + i * tw - 5 : tile + own + i - 5 * tw);
 #pragma unroll
             for (int jj = 0; jj < 6; jj++)
-                asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"(jj * 2 * (PM_RW + 10) * 2), "v"(bz));
+                asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"(ROW ? jj * 4 : jj * 2 * (PM_RW + 10) * 2), "v"(bz));
         }
         float ax[6], ay[6];
         uint32_t q[6];
         if (V & 32) __builtin_amdgcn_s_setprio(3);               // a wave computing tap positions / issuing gathers goes ahead of waves that are blending
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 1: tap positions -> byte offsets; phase 2: gathers
-            const float yj = (float)(y + 2 * jj - 5);
-            const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
+            const float yj = (float)((ROW ? x : y) + 2 * jj - 5);
+            const float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
             float u, v;
             int iu, iv;
             // Clamp range.  The oracle clamps to [-1, w] (tex2D at u + .5 with clamp addressing).  With variant bit 6 the byte
@@ -289,7 +297,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                     else
                         asm("s_waitcnt lgkmcnt(0)" : "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(s));
                 }
-                r = (V & 8) ? rcol[jj] : tile_value(tile[own + (2 * jj - 5) * tw + i]);
+                r = (V & 8) ? rcol[jj] : tile_value(ROW ? tile[own + i * tw + (2 * jj - 5)] : tile[own + (2 * jj - 5) * tw + i]);
             } else if (V & 8) {
                 // tied to s so that the wait cannot be scheduled ahead of the gather's return, by which time the LDS
                 // loads issued at the top of the column have long completed

@@ -269,7 +269,8 @@ template <int NB, int HR>
 static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
     // The production configuration (8-bit quad textures, box 11, <= 2 best views) runs the hand-scheduled tap loop of
-    // pm_core.h view_cost, in both arithmetic modes: variant 122 (114 where the D16 probe fails).  In strict mode it is
+    // pm_core.h view_cost, in both arithmetic modes: variant 250 in fast mode (row-wise walk), 122 in strict mode, 114 where
+    // the D16 probe fails.  In strict mode it is
     // the oracle's arithmetic (IEEE divides, min/max, floor) with the same loads, clamp-free loop and priorities: same
     // bits as the generic strict kernel.
     if (quad && NB == 2 && HR == 5) {
@@ -277,11 +278,14 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
         const int tiles256 = ((ctx->hscene.w + PM_RW - 1) / PM_RW) * ((ctx->hscene.h + 15) / 16);
         bool small = tiles256 < SWEEP_SMALL_IMAGE_TILES;
         if (const char* e = getenv("TSAR_BLOCK")) small = atoi(e) == 128;
-        if (small && ctx->variant == 122) {
-            return strict ? launch_sweep_t<2, 5, true, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
+        if (small && (ctx->variant == 250 || ctx->variant == 122)) {
+            if (strict) return launch_sweep_t<2, 5, true, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
+            return ctx->variant == 250 ? launch_sweep_t<2, 5, false, true, 250, 128>(ctx, colour, a, b, c, sid, dp, dr)
+                                       : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
         }
         if (strict) {
             switch (ctx->variant) {
+                case 250:       // the row-wise walk is a fast-mode liberty: strict runs the same loop in the oracle's column order
                 case 122: return launch_sweep_t<2, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
                 case 114: return launch_sweep_t<2, 5, true, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS
@@ -294,6 +298,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             switch (ctx->variant) {
                 case 122: return launch_sweep_t<2, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
                 case 114: return launch_sweep_t<2, 5, false, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
+                case 250: return launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
                 case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
                 case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);

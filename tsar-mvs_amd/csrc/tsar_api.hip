@@ -211,7 +211,7 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
 #ifdef TSAR_EXPERIMENTS
     if (const char* e = getenv("TSAR_LDS_SWEEP")) ctx->lds_sweep = e[0] == '1';
 #endif
-    ctx->variant = probe_d16_hi_zeroes(ctx) ? 122 : 114;
+    ctx->variant = probe_d16_hi_zeroes(ctx) ? 250 : 114;
     if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
     if (const char* e = getenv("TSAR_STRIP")) ctx->strip_w = atoi(e);
     if (const char* e = getenv("TSAR_DEBUG_COUNTERS"))
