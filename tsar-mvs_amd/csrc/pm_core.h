@@ -270,6 +270,16 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             if (!(V & 64)) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
             if (V & 64) {                                       // base already holds the border offset: the byte offset is a plain shift
                 const uint32_t off2 = (uint32_t)lin << 2;
+                if ((V & 256) && (jj & 1)) {
+                    // EXPERIMENT (TSAR_VARIANT=506, wrong results): the upper bound of pairing two taps of a row into one wide gather
+                    // — odd taps issue no load, a 16-byte load replaces the even tap's; the odd tap's offset arithmetic stands
+                    // in for the dword-select instructions a real pairing would need
+                    q[jj] = q[jj - 1] + off2;
+                } else if (V & 256) {
+                    typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4a4 wide = *(const u32x4a4 __attribute__((address_space(1)))*)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off2);
+                    q[jj] = wide.x ^ (wide.y & wide.z & wide.w & 0x01010101u);
+                } else
                 q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off2);
             } else if (V & 4) q[jj] = off * 2654435761u;        // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
             else q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);

@@ -300,6 +300,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
                 case 114: return launch_sweep_t<2, 5, false, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
                 case 250: return launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
+                case 506: return launch_sweep_t<2, 5, false, true, 506>(ctx, colour, a, b, c, sid, dp, dr);
                 case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
                 case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
                 case 10: return launch_sweep_t<2, 5, false, true, 10>(ctx, colour, a, b, c, sid, dp, dr);
