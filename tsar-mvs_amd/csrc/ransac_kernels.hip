@@ -22,12 +22,14 @@
 #define RS_BLOCK 1024
 #define RS_MAXPTS 49999
 
-struct ReliableTexturelessPixel {
-    const int32_t* canny;
-    const float* scale;
-    const int32_t* slot_of_region;
-    __device__ bool operator()(const uint32_t& p) const { return scale[p] == 1.0f && slot_of_region[canny[p]] >= 0; }
-};
+// flag[p] = 1 where pixel p is reliable (scale == 1) and lies in a textureless region (main.cpp:1527-1536); a plain streaming
+// kernel, so that the compaction itself is rocPRIM's flagged select over bytes (the predicate form, with its two dependent
+// gathers per element inside the select kernel, took 6 ms over 24 M pixels)
+__global__ void ransac_flag_kernel(const int32_t* __restrict__ canny, const float* __restrict__ scale, const int32_t* __restrict__ slot_of_region,
+                                   size_t np, uint8_t* __restrict__ flag) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (size_t)gridDim.x * blockDim.x)
+        flag[p] = (scale[p] == 1.0f && slot_of_region[canny[p]] >= 0) ? 1 : 0;
+}
 
 __global__ void ransac_keys_kernel(const uint32_t* __restrict__ pix, int n, const int32_t* __restrict__ canny,
                                    const int32_t* __restrict__ slot_of_region, uint32_t* __restrict__ keys, int* __restrict__ counts) {
@@ -393,15 +395,17 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         hipMemcpyAsync(d_region_of_slot, region_of_slot.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
         hipMemsetAsync(d_counts, 0, (size_t)nslot * 4, st);
         // (1) raster-order list of reliable pixels inside textureless regions (main.cpp:1527-1536)
-        ReliableTexturelessPixel pred{ctx->canny, ctx->scale, d_slot_of_region};
+        uint8_t* d_flag = (uint8_t*)dmalloc(np);
+        if (!d_flag) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
         size_t tmp_bytes = 0;
         rocprim::counting_iterator<uint32_t> first(0);
-        if (rocprim::select(nullptr, tmp_bytes, first, d_pix, d_nsel, np, pred, st) != hipSuccess) return done(TSAR_ERR_HIP, "rocprim::select sizing failed");
+        if (rocprim::select(nullptr, tmp_bytes, first, d_flag, d_pix, d_nsel, np, st) != hipSuccess) return done(TSAR_ERR_HIP, "rocprim::select sizing failed");
         void* d_tmp = dmalloc(tmp_bytes);
         if (!d_tmp) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
         {
             ScopedKernelTimer tm(ctx, "ransac_select");
-            if (rocprim::select(d_tmp, tmp_bytes, first, d_pix, d_nsel, np, pred, st) != hipSuccess) return done(TSAR_ERR_HIP, "rocprim::select failed");
+            hipLaunchKernelGGL(ransac_flag_kernel, dim3(2048), dim3(256), 0, st, ctx->canny, ctx->scale, d_slot_of_region, np, d_flag);
+            if (rocprim::select(d_tmp, tmp_bytes, first, d_flag, d_pix, d_nsel, np, st) != hipSuccess) return done(TSAR_ERR_HIP, "rocprim::select failed");
         }
         uint32_t nsel = 0;
         hipMemcpyAsync(&nsel, d_nsel, 4, hipMemcpyDeviceToHost, st);
