@@ -358,6 +358,45 @@ def test_view_subset_change_mid_run_bit_exact(mid_scene):
     m.close()
 
 
+def test_device_buffers_and_final_mode_with_device_inputs(small_scene):
+    """the ABI pieces tsar_gipuma --all --fuse is built from (device alloc / host write / peer copy, here on one device), and
+    tsar_pm_iterate_final fed from device memory"""
+    import ctypes as C
+    import torch
+    L = api.load_library()
+    n = 1 << 16
+    src = np.arange(n, dtype=np.float32)
+    a = L.tsar_device_alloc(0, n * 4)
+    b = L.tsar_device_alloc(0, n * 4)
+    assert a and b
+    assert L.tsar_device_write(0, a, src.ctypes.data_as(C.c_void_p), n * 4) == api.TSAR_OK
+    assert L.tsar_peer_copy(0, b, 0, a, n * 4) == api.TSAR_OK
+    back = torch.empty(n, dtype=torch.float32, device="cuda")
+    assert L.tsar_peer_copy(0, C.c_void_p(back.data_ptr()), 0, b, n * 4) == api.TSAR_OK
+    assert np.array_equal(back.cpu().numpy(), src)
+    assert L.tsar_peer_copy(0, None, 0, a, 4) == api.TSAR_ERR_INVALID
+    L.tsar_device_free(0, a)
+    L.tsar_device_free(0, b)
+    pinned = api.pinned_empty((4, 5), np.float32)
+    pinned[...] = 3.0
+    view = pinned[1:]                              # a view keeps the page-locked block alive
+    del pinned
+    assert float(view.sum()) == 45.0
+    # final-mode iterations with lines->text living on the device
+    sc = small_scene
+    text = np.zeros((sc.h, sc.w), np.float32)
+    text[::3] = -1.0
+    orc = _oracle(sc, seed=2)
+    orc.pm_init()
+    orc.pm_iterate_final(1, text)
+    m = api.matcher_from_scene(sc, seed=2, flags=api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate_final(1, torch.from_numpy(text).cuda())
+    planes, cost, _, _ = m.get_plane()
+    assert np.array_equal(cost, orc.c) and np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+    m.close()
+
+
 def test_error_codes(small_scene):
     m = api.Matcher()
     with pytest.raises(api.TsarError) as e:
