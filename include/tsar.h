@@ -101,6 +101,11 @@ extern "C" {
 #define TSAR_FLAG_NO_LINE_CLOSING    (1u << 4) /* tsar_detect_weak_texture: skip the Hough boundary closing of large regions
                                                   (main.cpp:385-435; on by default like the reference's HoughLinesP step) */
 
+#define TSAR_FLAG_TEX_FILTER_8BIT    (1u << 5) /* bilinear fractions rounded to 8 fractional bits before the blend, as the CUDA
+                                                  texture unit the reference samples through stores them (linear filtering with
+                                                  1.8 fixed-point weights, main.cpp:1215-1219); the unit's rounding rule is
+                                                  unpublished: round-to-nearest-even here.  Runs the generic kernels (slower). */
+
 typedef struct tsar_ctx tsar_ctx;
 
 /* One calibrated view as read from an MVSNet-style cams/%08d_cam.txt (reference

@@ -20,7 +20,9 @@
  *   S2 propagation reads neighbours from the state as it was when the launch started (Jacobi);
  *      the reference races on same-colour neighbours (gipuma.cu:958-1034).
  *   S3 image reads: clamp-to-edge addressing, exact fp32 bilinear weights (CUDA uses 8 fractional
- *      bits; tex2D does not exist on gfx950).
+ *      bits; tex2D does not exist on gfx950).  S3' (ORC_FLAG_TEX_FILTER_8BIT): the two filter
+ *      fractions are rounded to 8 fractional bits first, as the CUDA texture unit stores them
+ *      (1.8 fixed point); its rounding rule is unpublished, round-to-nearest-even is used here.
  *   S4 fused multiply-adds appear exactly where fmaf() is written here; everything else is a
  *      single IEEE operation (compile with -ffp-contract=off).  rsqrtf -> 1/sqrtf, exp -> the
  *      polynomial orc_expf below (both sides of the parity check implement the same polynomial).
@@ -40,6 +42,7 @@
 #define ORC_MAXCOST 2.0f
 #define ORC_FLAG_FIX_DOWN_FAR_SEED (1u << 0)
 #define ORC_FLAG_FIX_RIGHT_FAR_CMP (1u << 1)
+#define ORC_FLAG_TEX_FILTER_8BIT (1u << 5)
 
 typedef struct {
     float K[9], Kinv[9], R[9], t[3]; /* pose relative to the reference camera (ref = K[I|0]) */
@@ -135,11 +138,12 @@ static inline float texel(const float *img, int w, int h, int x, int y) {
     return img[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)];
 }
 /* tex2D<float>(tex, u+0.5, v+0.5) with linear filtering, clamp addressing (main.cpp:1215-1219) */
-static inline float bilinear(const float *img, int w, int h, float u, float v) {
+static inline float bilinear_q(const float *img, int w, int h, float u, float v, int q8) {
     u = fminf(fmaxf(u, -1.0f), (float)w);
     v = fminf(fmaxf(v, -1.0f), (float)h);
     float fu = floorf(u), fv = floorf(v);
     float ax = u - fu, ay = v - fv;
+    if (q8) { ax = rintf(ax * 256.0f) * 0.00390625f; ay = rintf(ay * 256.0f) * 0.00390625f; } /* S3' */
     int x0 = (int)fu, y0 = (int)fv;
     float t00 = texel(img, w, h, x0, y0), t10 = texel(img, w, h, x0 + 1, y0);
     float t01 = texel(img, w, h, x0, y0 + 1), t11 = texel(img, w, h, x0 + 1, y0 + 1);
@@ -147,7 +151,9 @@ static inline float bilinear(const float *img, int w, int h, float u, float v) {
     float bot = fmaf(ax, t11 - t01, t01);
     return fmaf(ay, bot - top, top);
 }
+static inline float bilinear(const float *img, int w, int h, float u, float v) { return bilinear_q(img, w, h, u, v, 0); }
 float orc_bilinear(const float *img, int w, int h, float u, float v) { return bilinear(img, w, h, u, v); }
+float orc_bilinear_q8(const float *img, int w, int h, float u, float v) { return bilinear_q(img, w, h, u, v, 1); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* camera derivation (cameraGeometryUtils.h:270-356), double precision then rounded            */
@@ -276,7 +282,7 @@ static float pm_cost(const orc_state *s, int view, int x, int y, const float *n4
             float yj = (float)(y + j);
             float ref_pix = texel(l, w, h, x + i, y + j);
             float X = fmaf(H[1], yj, bx), Y = fmaf(H[4], yj, by), Z = fmaf(H[7], yj, bz);
-            float src_pix = bilinear(r, w, h, X / Z, Y / Z);
+            float src_pix = bilinear_q(r, w, h, X / Z, Y / Z, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
             float sd = sqrtf((float)(i * i + j * j));
             float cd = fabsf(ref_pix - cen);
             float wt = orc_expf(-sd / 50.0f - cd / 18.0f);
@@ -661,7 +667,7 @@ static float rl_cost(const orc_state *s, int view, int x, int y, const float *n4
     float xf = (float)x, yf = (float)y;
     float Zc = fmaf(H[7], yf, fmaf(H[6], xf, H[8]));
     float pcx = fmaf(H[1], yf, fmaf(H[0], xf, H[2])) / Zc, pcy = fmaf(H[4], yf, fmaf(H[3], xf, H[5])) / Zc;
-    float cen = bilinear(r, w, h, pcx, pcy);
+    float cen = bilinear_q(r, w, h, pcx, pcy, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
     float sum_ref = 0, sum_ref_ref = 0, sum_src = 0, sum_src_src = 0, sum_ref_src = 0, wsum = 0;
     for (int i = -s->hrad; i < s->hrad + 1; i += 2)
         for (int j = -s->vrad; j < s->vrad + 1; j += 2) {
@@ -672,7 +678,7 @@ static float rl_cost(const orc_state *s, int view, int x, int y, const float *n4
             float qx = (float)plx, qy = (float)ply;
             float Z = fmaf(V[7], qy, fmaf(V[6], qx, V[8]));
             float X = fmaf(V[1], qy, fmaf(V[0], qx, V[2])), Y = fmaf(V[4], qy, fmaf(V[3], qx, V[5]));
-            float src_pix = bilinear(l, w, h, X / Z, Y / Z);
+            float src_pix = bilinear_q(l, w, h, X / Z, Y / Z, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
             float sd = sqrtf((float)(i * i + j * j));
             float cd = fabsf(ref_pix - cen);
             float wt = orc_expf(-sd / 50.0f - cd / 18.0f);

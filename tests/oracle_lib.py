@@ -45,6 +45,8 @@ def lib():
         L.orc_expf.argtypes = [C.c_float]
         L.orc_bilinear.restype = C.c_float
         L.orc_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_bilinear_q8.restype = C.c_float
+        L.orc_bilinear_q8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         L.orc_pm_cost.restype = C.c_float
         L.orc_pm_cost.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_pm_cost_multiview.restype = C.c_float

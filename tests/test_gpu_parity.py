@@ -70,6 +70,36 @@ def test_cost_planes_fast_tolerance(small_scene):
     m.close()
 
 
+def test_8bit_texture_filter_mode_bit_exact(small_scene):
+    """TSAR_FLAG_TEX_FILTER_8BIT (S3'): the CUDA texture unit's 8-fractional-bit filter weights; strict arithmetic, whole
+    iterations and the reverse-direction cost"""
+    sc = small_scene
+    fl = api.FLAG_TEX_FILTER_8BIT
+    orc = _oracle(sc, seed=41, flags=fl)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    orc.lrdiff_op()
+    orc.getview()
+    m = api.matcher_from_scene(sc, seed=41, flags=fl | api.FLAG_STRICT_DIV)
+    m.pm_init()
+    m.pm_iterate(2)
+    planes, cost, bv, _ = m.get_plane()
+    assert np.array_equal(cost, orc.c) and np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32)) and np.array_equal(bv, orc.beview)
+    m.lrdiff()
+    m.getview()
+    m.compute_disp()
+    assert np.array_equal(m.get_result(("confid",))["confid"], orc.confid)
+    m.close()
+    plain = _oracle(sc, seed=41)
+    plain.pm_init()
+    plain.pm_iterate(2)
+    assert not np.array_equal(plain.c, orc.c)              # the mode does change the numbers
+    f = api.matcher_from_scene(sc, seed=41, flags=fl)        # fast arithmetic + 8-bit filter: within the fast-mode cost tolerance
+    c_fast, _, _ = f.pm_cost_planes(orc.norm4.copy())
+    f.close()
+    assert np.max(np.abs(c_fast - orc.c)) <= 1e-3
+
+
 def test_float_image_path_matches_quad_path(small_scene):
     """non-integral images take the 4-load float path; on integral images both paths must agree exactly"""
     sc = small_scene

@@ -230,6 +230,30 @@ def test_bilinear_semantics():
     assert f(float("nan"), 0) == 0.0                        # NaN coordinates are defined (clamped low)
 
 
+def test_bilinear_8bit_filter_mode():
+    """S3' (TSAR_FLAG_TEX_FILTER_8BIT): fractions rounded to 8 fractional bits before the blend, as a CUDA texture fetch with
+    linear filtering stores them (1.8 fixed point; CUDA C Programming Guide, "Linear Filtering")"""
+    img = np.array([[100, 200, 100, 100], [100, 200, 100, 100]], np.float32)
+    L = ol.lib()
+    q = lambda u, v: L.orc_bilinear_q8(img.ctypes.data_as(C.c_void_p), 4, 2, C.c_float(u), C.c_float(v))
+    f = lambda u, v: L.orc_bilinear(img.ctypes.data_as(C.c_void_p), 4, 2, C.c_float(u), C.c_float(v))
+    assert q(0.5, 0) == f(0.5, 0) == 150.0                  # 128/256 is exact
+    assert abs(f(0.3, 0) - 130.0) < 1e-4
+    assert q(0.3, 0) == np.float32(100.0) + np.float32(77.0 / 256.0) * np.float32(100.0)     # round(0.3 * 256) = 77
+    assert q(0.999, 0) == 200.0                             # 255.7 -> 256: the weight 1.0 is representable
+    assert q(0.001, 0) == 100.0
+
+
+def test_8bit_filter_mode_changes_costs_slightly(small_scene):
+    sc = small_scene
+    a, b = _orc(sc), _orc(sc, flags=32)
+    planes = synth.gt_planes(sc).numpy()
+    ca, _, _ = a.pm_cost_planes(planes)
+    cb, _, _ = b.pm_cost_planes(planes)
+    d = np.abs(ca - cb)
+    assert 0 < d.max() < 0.05 and np.median(d) < 2e-3       # same matcher, marginally different samples
+
+
 def test_refinement_step_count(small_scene):
     o = _orc(small_scene)
     n, dz = 0, o.max_disp / 2

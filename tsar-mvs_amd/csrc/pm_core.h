@@ -29,12 +29,13 @@ typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
 typedef const float __attribute__((address_space(1)))* global_f32_ptr;
 
 template <bool QUAD>
-DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u, float v) {
+DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u, float v, bool q8 = false) {
     // tex2D(tex, u + .5, v + .5), linear filter, clamp addressing (main.cpp:1215-1219).
     u = fminf(fmaxf(u, -1.0f), (float)w);
     v = fminf(fmaxf(v, -1.0f), (float)h);
     const float fu = floorf(u), fv = floorf(v);
-    const float ax = u - fu, ay = v - fv;
+    float ax = u - fu, ay = v - fv;
+    if (q8) { ax = rintf(ax * 256.0f) * 0.00390625f; ay = rintf(ay * 256.0f) * 0.00390625f; }   // TSAR_FLAG_TEX_FILTER_8BIT (wave-uniform)
     const int iu = (int)fu, iv = (int)fv;
     float t00, t10, t01, t11;
     if (QUAD) {
@@ -342,7 +343,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 u = X * rz;
                 v = Y * rz;
             }
-            const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v);
+            const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v, (sc->flags & TSAR_FLAG_TEX_FILTER_8BIT) != 0);
             const float r = tile_value(tile[own + j * tw + i]);
             const float wt = wts[tap * BLK];
             const float ws = wt * s;

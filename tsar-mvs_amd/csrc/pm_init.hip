@@ -89,10 +89,11 @@ static int launch_full_t(tsar_ctx* ctx, const float4* planes, float* c, float4* 
 template <int NB, int HR, bool INIT>
 static int launch_full_nh(tsar_ctx* ctx, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
+    const bool production = !(ctx->hscene.flags & TSAR_FLAG_TEX_FILTER_8BIT);   // the 8-bit filter mode runs the generic tap loop
     // the production configuration (8-bit quad textures, box 11, <= 2 best views) runs the sweep's tap loop (pm_core.h view_cost,
     // variant 250 (fast) / 122 (strict) / 114) in both arithmetic modes
-    if (quad && NB == 2 && HR == 5 && ctx->variant == 250 && !strict) return launch_full_t<2, 5, false, true, INIT, 250>(ctx, planes, c, n, bv, rt);
-    if (quad && NB == 2 && HR == 5 && (ctx->variant == 250 || ctx->variant == 122 || ctx->variant == 114)) {
+    if (production && quad && NB == 2 && HR == 5 && ctx->variant == 250 && !strict) return launch_full_t<2, 5, false, true, INIT, 250>(ctx, planes, c, n, bv, rt);
+    if (production && quad && NB == 2 && HR == 5 && (ctx->variant == 250 || ctx->variant == 122 || ctx->variant == 114)) {
         if (strict) return ctx->variant != 114 ? launch_full_t<2, 5, true, true, INIT, 122>(ctx, planes, c, n, bv, rt) : launch_full_t<2, 5, true, true, INIT, 114>(ctx, planes, c, n, bv, rt);
         return ctx->variant == 122 ? launch_full_t<2, 5, false, true, INIT, 122>(ctx, planes, c, n, bv, rt) : launch_full_t<2, 5, false, true, INIT, 114>(ctx, planes, c, n, bv, rt);
     }

@@ -273,7 +273,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     // the D16 probe fails.  In strict mode it is
     // the oracle's arithmetic (IEEE divides, min/max, floor) with the same loads, clamp-free loop and priorities: same
     // bits as the generic strict kernel.
-    if (quad && NB == 2 && HR == 5) {
+    if (quad && NB == 2 && HR == 5 && !(ctx->hscene.flags & TSAR_FLAG_TEX_FILTER_8BIT)) {   // (the 8-bit filter mode runs the generic tap loop)
         // small images: 128-thread workgroups (see SWEEP_SMALL_IMAGE_TILES); TSAR_BLOCK=128|256 forces a shape (A/B runs)
         const int tiles256 = ((ctx->hscene.w + PM_RW - 1) / PM_RW) * ((ctx->hscene.h + 15) / 16);
         bool small = tiles256 < SWEEP_SMALL_IMAGE_TILES;

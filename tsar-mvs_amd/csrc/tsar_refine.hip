@@ -25,7 +25,8 @@ DEVFN float reverse_cost(const DevScene* __restrict__ sc, const DevView& vw, int
     const float xf = (float)x, yf = (float)y;
     const float Zc = fma_(H[7], yf, fma_(H[6], xf, H[8]));
     const float pcx = fma_(H[1], yf, fma_(H[0], xf, H[2])) / Zc, pcy = fma_(H[4], yf, fma_(H[3], xf, H[5])) / Zc;
-    const float cen = sample_bilinear<QUAD>(vw, w, h, qp, pcx, pcy);
+    const bool q8 = (sc->flags & TSAR_FLAG_TEX_FILTER_8BIT) != 0;
+    const float cen = sample_bilinear<QUAD>(vw, w, h, qp, pcx, pcy, q8);
     float sum_ref = 0.f, sum_ref_ref = 0.f, sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f, wsum = 0.f;
     for (int i = -hr; i <= hr; i += 2)
         for (int j = -vr; j <= vr; j += 2) {
@@ -39,7 +40,7 @@ DEVFN float reverse_cost(const DevScene* __restrict__ sc, const DevView& vw, int
             float u, v;
             if (STRICT) { u = X / Z; v = Y / Z; }
             else { const float rz = __builtin_amdgcn_rcpf(Z); u = X * rz; v = Y * rz; }
-            const float src_pix = sample_bilinear<QUAD>(rv, w, h, qp, u, v);
+            const float src_pix = sample_bilinear<QUAD>(rv, w, h, qp, u, v, q8);
             const float sd = sqrtf((float)(i * i + j * j));
             const float cd = fabsf(ref_pix - cen);
             const float wt = tsar_expf(-sd / 50.0f - cd / 18.0f);

@@ -17,7 +17,7 @@
 //                      over xGMI (tsar_peer_copy) and fused there (tsar_fuse) into D/APD/APD_TSAR.ply — the fuser of
 //                      x/1.sh:30 without the round trip through .dmb files (which are still written)
 //   --num_consistent= --reproj_error= --depth_diff= --angle= --used_list=   the fuser's options (x/1.sh:20-30), for --fuse
-//   --seed=S, --strict, --fix-quirks
+//   --seed=S, --strict, --fix-quirks, --texture-filter-8bit (TSAR_FLAG_TEX_FILTER_8BIT)
 // Images: binary PGM (the image has no JPEG decoder; `python -m tsar_mvs_amd.io convert a.jpg a.pgm`).
 // A name ending in .jpg/.png is looked up as the same stem + .pgm.
 #include <stdint.h>
@@ -44,7 +44,7 @@ struct Options {
     std::string images_folder, mslp_folder, krt_file, output_folder;
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
-    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false;
+    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false, tex8 = false;
     tsar_fusion_params fusion{};
     int gpus = 1, workers = 2;      // --all: worker threads per GPU (file I/O of one view overlaps the kernels of another)
     uint64_t seed = 0;
@@ -70,7 +70,7 @@ static void mkdirs(const std::string& path) {
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
-           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [-color_processing] [--display_outputs]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [--texture-filter-8bit] [-color_processing] [--display_outputs]\n"
            "       tsar_gipuma --all [--gpus=N] [--fuse [--num_consistent=N --reproj_error=PX --depth_diff=REL --angle=DEG --used_list=0|1]]\n"
            "                   -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
@@ -119,6 +119,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         else if (starts("--used_list=")) o.fusion.used_list = atoi(a + 12);
         else if (!strcmp(a, "--strict")) o.strict = true;
         else if (!strcmp(a, "--fix-quirks")) o.fix_quirks = true;
+        else if (!strcmp(a, "--texture-filter-8bit")) o.tex8 = true;      // bilinear weights with 8 fractional bits, like the CUDA texture unit
         else if (!strcmp(a, "-images_folder") && i + 1 < argc) o.images_folder = argv[++i];
         else if (!strcmp(a, "-mslp_folder") && i + 1 < argc) o.mslp_folder = argv[++i];
         else if (!strcmp(a, "-krt_file") && i + 1 < argc) o.krt_file = argv[++i];
@@ -199,7 +200,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     p.n_best = o.n_best; p.cost_comb = o.cost_comb; p.cam_scale = o.cam_scale;
     p.depth_min = dmin; p.depth_max = dmax;
     p.seed = o.seed + (uint64_t)ref_id;
-    p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0);
+    p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0) |
+              (o.tex8 ? TSAR_FLAG_TEX_FILTER_8BIT : 0);
     if (tsar_set_params(ctx, &p) != TSAR_OK) return fail("tsar_set_params");
     if (tsar_set_views(ctx, n, w, h, ptrs.data(), TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
     if (!subset_slots.empty()) {
