@@ -150,6 +150,8 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          (init, the first sweep: neighbouring lanes' footprints are unrelated and L2 bandwidth is the bound) the six gathers
 //          of a trip reuse the lines the first one brought into L1.  Changes the summation order of the three tap sums, hence
 //          fast mode only; strict keeps the oracle's column order.
+//   bit 8: experiment (wrong results): the instruction mix of pairing two taps into one 16-byte gather
+//   bit 9: radius 5, with bits 3 and 6 — gathers of line t+1 issued before line t is blended (two register sets)
 // BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread])
 template <int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
@@ -326,6 +328,105 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         }
         tap += 6;
     };
+    // variant bit 9 (EXPERIMENT, built with TSAR_EXPERIMENTS only; correct results, slower): the same line, split in two so that
+    // the six gathers of line t+1 are issued BEFORE line t is blended — a wave then always has six to twelve gathers in flight and
+    // its own address arithmetic covers part of their latency, instead of leaving all of it to the other three waves of the SIMD.
+    // Two register sets (Trip) alternate.  Measured (profiles/r02): 128 VGPRs only with 56 spills around the tap loop, 40.5 ms
+    // (six lines written out) / 41.5 ms (rolled, two lines per trip) against 38.45 ms: at four waves per SIMD the gather latency is
+    // already covered, and the second register set costs more than it hides.  Needs bits 3 and 6.
+    struct Trip { uint32_t q[6]; float ax[6], ay[6]; };
+    auto issue_line = [&](int i, Trip& T, auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
+        const float xi = (float)((ROW ? y : x) + i);
+        const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) {
+            const float yj = (float)((ROW ? x : y) + 2 * jj - 5);
+            const float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
+            float u, v;
+            int iu, iv;
+            if (STRICT) {
+                u = X / Z;
+                v = Y / Z;
+                if (CLAMP) {
+                    u = fminf(fmaxf(u, 0.0f), (float)(w - 1));
+                    v = fminf(fmaxf(v, 0.0f), (float)(h - 1));
+                }
+                const float fu = floorf(u), fv = floorf(v);
+                T.ax[jj] = u - fu;
+                T.ay[jj] = v - fv;
+                iu = (int)fu;
+                iv = (int)fv;
+            } else {
+                const float rz = __builtin_amdgcn_rcpf(Z);
+                u = X * rz;
+                v = Y * rz;
+                if (CLAMP) {
+                    u = __builtin_amdgcn_fmed3f(u, 0.0f, (float)(w - 1));
+                    v = __builtin_amdgcn_fmed3f(v, 0.0f, (float)(h - 1));
+                }
+                T.ax[jj] = __builtin_amdgcn_fractf(u);
+                T.ay[jj] = __builtin_amdgcn_fractf(v);
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
+            }
+            int lin;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
+            T.q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + ((uint32_t)lin << 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto blend_line = [&](int i, Trip& T) {
+        const int line = (i + 5) >> 1;
+        float rcol[6];
+        f32x2 wcol[3];
+        {   // the line's nine LDS loads; H[2] (changes with every view and hypothesis) pins them to this evaluation
+            constexpr int U = BLK / 64, S = ROW ? 6 : 1;
+            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + (ROW ? line : 6 * line) * BLK);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(2 * U * S * k), "n"(2 * U * S * k + U * S), "v"(H[2]));
+            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(ROW ? tile + own + i * tw - 5 : tile + own + i - 5 * tw);
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++)
+                asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"(ROW ? jj * 4 : jj * 2 * (PM_RW + 10) * 2), "v"(H[2]));
+        }
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++) {
+            float t00, t10, t01, t11;
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(T.q[jj]));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(T.q[jj]));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(T.q[jj]));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(T.q[jj]));
+            const float top = fma_(T.ax[jj], t10 - t00, t00);
+            const float bot = fma_(T.ax[jj], t11 - t01, t01);
+            float s = fma_(T.ay[jj], bot - top, top);
+            if (jj == 0)
+                asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[0]), "+v"(rcol[1]), "+v"(rcol[2]), "+v"(rcol[3]), "+v"(rcol[4]), "+v"(rcol[5]),
+                    "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(s));
+            const float r = rcol[jj];
+            const float wt = wcol[jj >> 1][jj & 1];
+            const float ws = wt * s;
+            sum_src += ws;
+            sum_src_src = fma_(ws, s, sum_src_src);
+            if (STRICT) sum_ref_src = fma_(wt * r, s, sum_ref_src);
+            else sum_ref_src = fma_(ws, r, sum_ref_src);
+        }
+    };
+    auto pipelined_lines = [&](auto clamp_tag) {
+        Trip A, B;
+        issue_line(-5, A, clamp_tag);
+#pragma unroll 1
+        for (int i = -5; i <= 3; i += 4) {          // two lines per trip: the hot code stays ~2.5 KB (six unrolled lines cost the i-cache more than they saved)
+            issue_line(i + 2, B, clamp_tag);
+            blend_line(i, A);
+            if (i < 3) issue_line(i + 4, A, clamp_tag);
+            blend_line(i + 2, B);
+        }
+    };
     // any window, both arithmetic modes, float or quad images: one tap at a time in the oracle's order
     auto column = [&](int i) {
         const float xi = (float)(x + i);
@@ -354,7 +455,10 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             ++tap;
         }
     };
-    if (FAST6) {
+    if (FAST6 && (V & 512)) {
+        if (need_clamp) pipelined_lines(std::true_type());
+        else pipelined_lines(std::false_type());
+    } else if (FAST6) {
         if (need_clamp) {
 #pragma unroll 1
             for (int i = -5; i <= 5; i += 2) column_fast(i, std::true_type());

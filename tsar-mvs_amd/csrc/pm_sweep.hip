@@ -133,7 +133,7 @@ DEVFN bool same_bits(const float4& a, const float4& b) {
 }
 
 template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
-__global__ __launch_bounds__(BLK) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
+__global__ __launch_bounds__(BLK, ((V & 512) ? 1024 / BLK : 1)) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
                                                             const float* __restrict__ c_same, const float4* __restrict__ n_same,
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
@@ -300,6 +300,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
                 case 114: return launch_sweep_t<2, 5, false, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
                 case 250: return launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
+                case 762: return launch_sweep_t<2, 5, false, true, 762>(ctx, colour, a, b, c, sid, dp, dr);
                 case 506: return launch_sweep_t<2, 5, false, true, 506>(ctx, colour, a, b, c, sid, dp, dr);
                 case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
                 case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
