@@ -111,7 +111,7 @@ def host_boundary(args, sc):
     """One step through the C ABI the way a host caller without device pointers uses it: images handed over as host
     buffers (H2D + quad-texture build inside tsar_set_views), results copied back to host (D2H inside tsar_get_result).
     Reported next to `value`, never as `value` (which is measured with inputs resident in HBM).  Two legs: the caller's
-    buffers page-locked (tsar_host_alloc — what tsar_gipuma does) and plain pageable memory."""
+    buffers page-locked (tsar_host_alloc — what host/tsar_gipuma.cpp does) and plain pageable memory."""
     from tsar_mvs_amd import api
     w, h = args.width, args.height
     pageable = [im.cpu().numpy() for im in sc.images]

@@ -51,7 +51,8 @@ static inline bool read_pairs(const std::string& path, std::map<int, std::vector
     return true;
 }
 
-static inline bool read_pgm(const std::string& path, std::vector<float>& img, int& w, int& h) {
+template <class FloatVec>
+static inline bool read_pgm(const std::string& path, FloatVec& img, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     char magic[3] = {0};
@@ -81,7 +82,8 @@ static inline bool read_pgm(const std::string& path, std::vector<float>& img, in
 // Binary PPM (P6), one channel extracted.  -color_processing in the reference uploads float4 (B, G, R, alpha) textures
 // but the matching cost fetches them with tex2D<float> (gipuma.cu:247,262,265), i.e. it matches on the first channel of
 // OpenCV's BGR order: blue.  channel: 0 = R, 1 = G, 2 = B of the PPM.
-static inline bool read_ppm_channel(const std::string& path, int channel, std::vector<float>& img, int& w, int& h) {
+template <class FloatVec>
+static inline bool read_ppm_channel(const std::string& path, int channel, FloatVec& img, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     char magic[3] = {0};
