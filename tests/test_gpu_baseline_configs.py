@@ -302,3 +302,41 @@ def test_random_shapes_bit_exact():
         assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32)), ctx
         assert np.array_equal(bv, orc.beview), ctx
         m.close()
+
+
+def test_degenerate_inputs_bit_exact():
+    """edge cases of the boundary: the smallest accepted image, a textureless reference (every hypothesis scores MAXCOST, the
+    exported depth is 0 everywhere), 32 scored views out of 33 supplied (the width of the reference's cost vector)"""
+    # 8 x 8, one source view
+    sc = synth.make_scene(8, 8, 1, seed=3)
+    orc = _oracle(sc, seed=1)
+    orc.pm_init(); orc.pm_iterate(2)
+    m = api.matcher_from_scene(sc, seed=1, flags=api.FLAG_STRICT_DIV)
+    m.pm_init(); m.pm_iterate(2)
+    _assert_state_equal(m, orc)
+    m.close()
+    # flat reference image
+    sc = synth.make_scene(64, 48, 2, seed=4)
+    imgs = [im.clone() for im in sc.images]
+    imgs[0][:] = 77.0
+    orc = ol.Oracle([im.numpy() for im in imgs], sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2)
+    orc.pm_init(); orc.pm_iterate(1)
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=2, flags=api.FLAG_STRICT_DIV))
+    m.set_views(imgs, sc.K, sc.R, sc.t)
+    m.pm_init(); m.pm_iterate(1)
+    _assert_state_equal(m, orc)
+    m.compute_disp()
+    res = m.get_result(("depth", "cost"))
+    assert (res["cost"] == 2.0).all() and (res["depth"] == 0.0).all()
+    m.close()
+    # 33 source views: the default subset is the first 32; cost_comb ALL averages all 32 (the NB = 32 kernels)
+    sc = synth.make_scene(48, 32, 33, seed=5)
+    orc = _oracle(sc, seed=3, cost_comb=api.COMB_ALL, subset=list(range(1, 33)))
+    orc.pm_init(); orc.pm_iterate(1)
+    m = api.matcher_from_scene(sc, seed=3, cost_comb=api.COMB_ALL, flags=api.FLAG_STRICT_DIV)
+    m.pm_init(); m.pm_iterate(1)
+    _assert_state_equal(m, orc)
+    with pytest.raises(api.TsarError):
+        m.set_view_subset(list(range(1, 34)))
+    m.close()
