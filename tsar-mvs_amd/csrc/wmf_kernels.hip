@@ -34,6 +34,12 @@ DEVFN int slot_pixel(const WmfTaps& t, int k, int w) {
     const int ii = k / 11, jj = k - 11 * ii;
     return (t.y - t.radius + jj * t.gap) * w + (t.x - t.radius + ii * t.gap);
 }
+// the same for a slot number that comes out of the ranking (per-lane): never outside the image, whatever the list held
+DEVFN int slot_pixel_safe(const WmfTaps& t, int k, int w, int h) {
+    const int ii = k / 11, jj = k - 11 * ii;
+    const int px = min(max(t.x - t.radius + ii * t.gap, 0), w - 1), py = min(max(t.y - t.radius + jj * t.gap, 0), h - 1);
+    return py * w + px;
+}
 enum WmfList { WMF_DEPTH = 0, WMF_NX = 1, WMF_NY = 2, WMF_NZ = 3 };
 template <int LIST>
 DEVFN float slot_value(const float* __restrict__ depth_in, const float4* __restrict__ n_in, int q) {
@@ -159,7 +165,8 @@ DEVFN void rank_order(const float* __restrict__ depth_in, const float4* __restri
             if (k0 + c < WMF_SLOTS && slot_valid(t, k0 + c)) l.pos[r[c] * WMF_BLOCK + tid] = (unsigned char)(k0 + c);
     }
 }
-DEVFN int pos_at(const WmfLds& l, int i) { return l.pos[i * WMF_BLOCK + threadIdx.x]; }
+// clamped: with NaN values in a list the counted ranks are no permutation and a rank may stay unwritten (stale LDS byte)
+DEVFN int pos_at(const WmfLds& l, int i) { return min((int)l.pos[i * WMF_BLOCK + threadIdx.x], WMF_SLOTS - 1); }
 // Cumulative weight in rank order (gipuma.cu:1618-1650): acc += w[pos[i]] for i = 0 .. num-1, sequentially — the fp32 sums must
 // be formed in exactly this order.  Each step is an LDS read (the slot) feeding a scratch read (its weight) at a per-lane
 // address; taken one at a time that is ~1.5 us of latency per step (the weights of all resident waves do not fit L2).  So the
@@ -198,8 +205,8 @@ DEVFN int weighted_median_slot(const float* w, const WmfLds& l, int num, float h
     return k;
 }
 template <int LIST>
-DEVFN float value_of_slot(const float* __restrict__ depth_in, const float4* __restrict__ n_in, int w, const WmfTaps& t, int k) {
-    return k == WMF_SLOTS - 1 ? 0.0f : slot_value<LIST>(depth_in, n_in, slot_pixel(t, k, w));
+DEVFN float value_of_slot(const float* __restrict__ depth_in, const float4* __restrict__ n_in, int w, int h, const WmfTaps& t, int k) {
+    return k == WMF_SLOTS - 1 ? 0.0f : slot_value<LIST>(depth_in, n_in, slot_pixel_safe(t, k, w, h));
 }
 
 DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict__ scale_in, int x, int y, int radius, int gap, float sdiv, WmfTaps& t) {
@@ -261,15 +268,15 @@ DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict
                 if (i0 + u < num && !found && acc >= half) { found = true; kf = k[u]; }
             }
         }
-        if (found) weimid = kf == WMF_SLOTS - 1 ? 0 : slot_pixel(t, kf, w);   // n[] of the zero slot is 0
+        if (found) weimid = kf == WMF_SLOTS - 1 ? 0 : slot_pixel_safe(t, kf, w, sc->h);   // n[] of the zero slot is 0
     }
     float nm[3];
     rank_order<WMF_NX>(depth_in, n_in, w, t, l);
-    nm[0] = value_of_slot<WMF_NX>(depth_in, n_in, w, t, weighted_median_slot(t.w, l, num, half));
+    nm[0] = value_of_slot<WMF_NX>(depth_in, n_in, w, sc->h, t, weighted_median_slot(t.w, l, num, half));
     rank_order<WMF_NY>(depth_in, n_in, w, t, l);
-    nm[1] = value_of_slot<WMF_NY>(depth_in, n_in, w, t, weighted_median_slot(t.w, l, num, half));
+    nm[1] = value_of_slot<WMF_NY>(depth_in, n_in, w, sc->h, t, weighted_median_slot(t.w, l, num, half));
     rank_order<WMF_NZ>(depth_in, n_in, w, t, l);
-    nm[2] = value_of_slot<WMF_NZ>(depth_in, n_in, w, t, weighted_median_slot(t.w, l, num, half));
+    nm[2] = value_of_slot<WMF_NZ>(depth_in, n_in, w, sc->h, t, weighted_median_slot(t.w, l, num, half));
     if (weimid < 0) return false;
     const float depth_mid = rf.f * rf.baseline / depth_in[weimid];
     const double nrm = (double)sqrtf(dot3(nm, nm));   // `double xyzsqr = sqrtf(..)`, gipuma.cu:1663-1666
