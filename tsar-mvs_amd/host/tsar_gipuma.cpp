@@ -191,6 +191,31 @@ struct ImageCache {
 };
 static ImageCache g_images;
 
+// --all: every GPU keeps every image of the scene it has used resident (44 x 97.5 MB = 4.3 GB at ETH3D size, of
+// 288 GB), uploaded once; a view then hands device pointers to tsar_set_views instead of pushing its 1 + N images over PCIe
+// again (a scene's images are each the reference once and a source ~N times).
+struct DeviceImageCache {
+    std::mutex mu;
+    std::map<std::pair<int, std::string>, float*> items;        // (device, path) -> device copy
+    const float* get(int device, const std::string& path, const ImageCache::Entry& host) {
+        std::lock_guard<std::mutex> lk(mu);                       // uploads are rare (once per image and device): serialised
+        auto it = items.find({device, path});
+        if (it != items.end()) return it->second;
+        const size_t bytes = (size_t)host.w * host.h * sizeof(float);
+        float* d = (float*)tsar_device_alloc(device, bytes);
+        if (!d) return nullptr;
+        if (tsar_device_write(device, d, host.gray.data(), bytes) != TSAR_OK) { tsar_device_free(device, d); return nullptr; }
+        items[{device, path}] = d;
+        return d;
+    }
+    void release() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& kv : items) tsar_device_free(kv.first.first, kv.second);
+        items.clear();
+    }
+};
+static DeviceImageCache g_device_images;
+
 // --fuse: what a matched view leaves on its GPU for the gather (device memory, owned by the run)
 struct DeviceResult {
     int device = -1, w = 0, h = 0;
@@ -216,7 +241,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     const auto t0 = std::chrono::steady_clock::now();
     const int n = (int)names.size();
     std::vector<std::shared_ptr<ImageCache::Entry>> gray(n);
-    std::vector<const float*> ptrs(n);
+    std::vector<const float*> ptrs(n), dev_ptrs;
     std::vector<tsar_camera> cams(n);
     int w = 0, h = 0;
     float dmin = o.depth_min, dmax = o.depth_max;
@@ -228,6 +253,10 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         if (i == 0) { w = wi; h = hi; }
         if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); return -1; }
         ptrs[i] = gray[i]->gray.data();
+        if (reuse && reuse->shared_ctx) {                         // --all: resident device copy (falls back to the host buffer)
+            const float* d = g_device_images.get(device, ip, *gray[i]);
+            if (d) dev_ptrs.push_back(d);
+        }
         CamFile cf;
         const std::string cp = o.mslp_folder + "cams/" + stem8(names[i]) + "_cam.txt";
         if (!read_cam(cp, cf)) { fprintf(stderr, "cannot read camera %s\n", cp.c_str()); return -1; }
@@ -254,7 +283,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0) |
               (o.tex8 ? TSAR_FLAG_TEX_FILTER_8BIT : 0);
     if (tsar_set_params(ctx, &p) != TSAR_OK) return fail("tsar_set_params");
-    if (tsar_set_views(ctx, n, w, h, ptrs.data(), TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
+    const bool resident = (int)dev_ptrs.size() == n;
+    if (tsar_set_views(ctx, n, w, h, resident ? dev_ptrs.data() : ptrs.data(), resident ? TSAR_MEM_DEVICE : TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
     if (!subset_slots.empty()) {
         std::vector<int32_t> s(subset_slots.begin(), subset_slots.end());
         if (tsar_set_view_subset(ctx, (int)s.size(), s.data()) != TSAR_OK) return fail("tsar_set_view_subset");
@@ -370,6 +400,7 @@ int main(int argc, char** argv) {
                 tsar_destroy(worker_ctx);
             });
         for (auto& t : th) t.join();
+        g_device_images.release();
         for (int s : status)
             if (s != 0) return 1;
         if (o.fuse) {
