@@ -99,7 +99,7 @@ class Oracle:
     """Host-side mirror of the matcher state used by the parity tests."""
 
     def __init__(self, images, K, R, t, depth_min, depth_max, box=11, n_best=1, cost_comb=1, flags=0, seed=2024,
-                 cam_scale=1.0, subset=None):
+                 cam_scale=1.0, subset=None, box_v=None):
         L = lib()
         self.L = L
         self.images = [np.ascontiguousarray(np.asarray(im, dtype=np.float32)) for im in images]
@@ -112,7 +112,7 @@ class Oracle:
         R = np.ascontiguousarray(R, dtype=np.float32)
         t = np.ascontiguousarray(t, dtype=np.float32)
         L.orc_derive_cameras(self.s, self.n_views, _p(K), _p(R), _p(t), C.c_float(cam_scale), C.c_float(depth_min), C.c_float(depth_max))
-        L.orc_set_params(self.s, box, box, n_best, cost_comb, flags, seed)
+        L.orc_set_params(self.s, box, box if box_v is None else box_v, n_best, cost_comb, flags, seed)
         if subset is None:
             subset = list(range(1, self.n_views))
         sub = np.asarray(subset, dtype=np.int32)

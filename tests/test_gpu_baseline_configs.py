@@ -191,37 +191,41 @@ def test_lds_patch_sweep_variant_bit_exact(monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("box,n_best,n_src", [(19, 2, 3), (7, 1, 3), (11, 1, 1), (11, 3, 5), (5, 1, 2)])
+@pytest.mark.parametrize("box,n_best,n_src", [(19, 2, 3), (7, 1, 3), (11, 1, 1), (11, 3, 5), (5, 1, 2), (9, 1, 2), (15, 4, 5), (27, 1, 2), ((13, 7), 2, 3)])
 def test_other_windows_and_view_counts_bit_exact(box, n_best, n_src):
-    """the generic kernels: runtime window radius (the reference's default box 19 = 100 taps, LDS 100 KiB per
-    workgroup), best-N lists longer than two, and a single source view (ratio is defined as 0 there)"""
+    """the general-window kernels (pm_core_lut.h: runtime radius — the reference's default box is 19 = 100 taps —, weights from
+    the shared table, chunked lines), best-N lists longer than two, and a single source view (ratio is defined as 0 there,
+    DESIGN.md §3)"""
     sc = synth.make_scene(112, 80, n_src, seed=31)
-    orc = _oracle(sc, seed=9, box=box, n_best=n_best)
+    box, box_v = box if isinstance(box, tuple) else (box, box)
+    orc = _oracle(sc, seed=9, box=box, box_v=box_v, n_best=n_best)
     orc.pm_init()
     orc.pm_iterate(2)
-    m = api.matcher_from_scene(sc, seed=9, box=box, n_best=n_best, flags=api.FLAG_STRICT_DIV)
+    m = api.matcher_from_scene(sc, seed=9, box=box, box_v=box_v, n_best=n_best, flags=api.FLAG_STRICT_DIV)
     m.pm_init()
     m.pm_iterate(2)
     _assert_state_equal(m, orc)
     m.close()
 
 
-def test_non_integral_images_bit_exact():
-    """images that are not an 8-bit decode take the float path (four loads per bilinear tap, float reference window)"""
+@pytest.mark.parametrize("box", [11, 7, 19])
+def test_non_integral_images_bit_exact(box):
+    """images that are not an 8-bit decode take the float path (four loads per bilinear tap, float reference window, S hoisted
+    weights per thread in LDS), whatever the box"""
     sc = synth.make_scene(112, 80, 3, seed=33)
     rng = np.random.default_rng(0)
     sc.images = [im + torch.from_numpy(rng.uniform(0, 0.5, size=tuple(im.shape)).astype(np.float32)) for im in sc.images]
-    orc = _oracle(sc, seed=9)
+    orc = _oracle(sc, seed=9, box=box)
     orc.pm_init()
     orc.pm_iterate(2)
     for flags in (api.FLAG_STRICT_DIV,):
-        m = api.matcher_from_scene(sc, seed=9, flags=flags)
+        m = api.matcher_from_scene(sc, seed=9, box=box, flags=flags)
         m.pm_init()
         m.pm_iterate(2)
         _assert_state_equal(m, orc)
         m.close()
     # fast mode on the float path: same plane scored within the documented tolerance
-    f = api.matcher_from_scene(sc, seed=9)
+    f = api.matcher_from_scene(sc, seed=9, box=box)
     c_fast, _, _ = f.pm_cost_planes(orc.norm4)
     c_ref, _, _ = orc.pm_cost_planes(orc.norm4)
     assert np.max(np.abs(c_fast - c_ref)) <= 2e-3

@@ -44,11 +44,17 @@ def _random_planes(scene, orc, seed):
     return planes
 
 
-@pytest.mark.parametrize("box,n_best,comb", [(11, 1, 1), (11, 2, 1), (7, 3, 1), (11, 1, 0), (19, 2, 1), (11, 1, 2), (11, 1, 3)])
+# boxes other than 11 (and more than two best views) run the general-window tap loop: weights from the shared table, lines in
+# chunks of 4 / 5 / 6 taps (pm_core_lut.h).  (box, box_v): line lengths 1..16 taps cover every chunk length and padding count;
+# even radii put the centre pixel among the taps; 25 and 31 are beyond what the per-thread weight table could hold.
+@pytest.mark.parametrize("box,n_best,comb", [(11, 1, 1), (11, 2, 1), (7, 3, 1), (11, 1, 0), (19, 2, 1), (11, 1, 2), (11, 1, 3),
+                                             (1, 1, 1), (3, 1, 1), (5, 2, 1), (9, 1, 1), (13, 1, 1), (15, 2, 1), (17, 1, 0), (21, 1, 1),
+                                             (23, 4, 1), (25, 1, 1), (31, 2, 1), ((7, 13), 1, 1), ((19, 5), 2, 1), ((3, 27), 1, 1)])
 def test_cost_planes_strict_bit_exact(small_scene, box, n_best, comb):
     sc = small_scene
-    orc = _oracle(sc, box=box, n_best=n_best, cost_comb=comb)
-    m = api.matcher_from_scene(sc, box=box, n_best=n_best, cost_comb=comb, flags=api.FLAG_STRICT_DIV)
+    box, box_v = box if isinstance(box, tuple) else (box, box)
+    orc = _oracle(sc, box=box, box_v=box_v, n_best=n_best, cost_comb=comb)
+    m = api.matcher_from_scene(sc, box=box, box_v=box_v, n_best=n_best, cost_comb=comb, flags=api.FLAG_STRICT_DIV)
     for planes in (synth.gt_planes(sc).numpy(), _random_planes(sc, orc, 3)):
         c_ref, bv_ref, rt_ref = orc.pm_cost_planes(planes)
         c, bv, rt = m.pm_cost_planes(planes)
@@ -58,10 +64,12 @@ def test_cost_planes_strict_bit_exact(small_scene, box, n_best, comb):
     m.close()
 
 
-def test_cost_planes_fast_tolerance(small_scene):
+@pytest.mark.parametrize("box,n_best", [(11, 1), (19, 2), (7, 1), (9, 3), (11, 3), ((15, 9), 1), (25, 1)])
+def test_cost_planes_fast_tolerance(small_scene, box, n_best):
     sc = small_scene
-    orc = _oracle(sc)
-    m = api.matcher_from_scene(sc)
+    box, box_v = box if isinstance(box, tuple) else (box, box)
+    orc = _oracle(sc, box=box, box_v=box_v, n_best=n_best)
+    m = api.matcher_from_scene(sc, box=box, box_v=box_v, n_best=n_best)
     for planes in (synth.gt_planes(sc).numpy(), _random_planes(sc, orc, 5)):
         c_ref, bv_ref, _ = orc.pm_cost_planes(planes)
         c, bv, _ = m.pm_cost_planes(planes)
@@ -435,15 +443,23 @@ def test_error_codes(small_scene):
     with pytest.raises(api.TsarError) as e:
         m.set_params(api.default_params(depth_min=5.0, depth_max=1.0))
     assert e.value.code == api.TSAR_ERR_INVALID
-    # limits that used to fail late or silently: more best views than the 32-entry cost vector, a box whose weight table
-    # cannot fit the LDS of a CU
-    for bad in (dict(n_best=33), dict(box_hsize=25, box_vsize=25), dict(box_hsize=63, box_vsize=11)):
+    # limits that used to fail late or silently: more best views than the 32-entry cost vector, a box beyond 63
+    for bad in (dict(n_best=33), dict(box_hsize=65, box_vsize=11), dict(box_hsize=11, box_vsize=0)):
         with pytest.raises(api.TsarError) as e:
             m.set_params(api.default_params(**bad))
         assert e.value.code == api.TSAR_ERR_INVALID, bad
-    m.set_params(api.default_params(box_hsize=23, box_vsize=23))      # the largest square box is accepted
+    m.set_params(api.default_params(box_hsize=63, box_vsize=63))      # 8-bit imagery: any box (shared weight table)
     m.close()
     sc = small_scene
+    # images that are not an 8-bit decode keep S weights per thread in LDS: boxes beyond 23 are refused when the views arrive
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=25, box_vsize=25, depth_min=sc.depth_min, depth_max=sc.depth_max))
+    with pytest.raises(api.TsarError) as e:
+        m.set_views([im + 0.25 for im in sc.images], sc.K, sc.R, sc.t)
+    assert e.value.code == api.TSAR_ERR_INVALID
+    m.set_params(api.default_params(box_hsize=23, box_vsize=23, depth_min=sc.depth_min, depth_max=sc.depth_max))
+    m.set_views([im + 0.25 for im in sc.images], sc.K, sc.R, sc.t)   # the largest square box of the float path
+    m.close()
     m = api.matcher_from_scene(sc)
     with pytest.raises(api.TsarError) as e:
         m.set_view_subset(list(range(1, 3)) * 17)                      # 34 entries

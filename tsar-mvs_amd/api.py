@@ -411,10 +411,10 @@ class Matcher:
         return {buf[i].name.decode(): (buf[i].launches, buf[i].total_ms) for i in range(min(n.value, 32))}
 
 
-def matcher_from_scene(scene, box=11, n_best=1, cost_comb=COMB_BEST_N, flags=0, seed=2024, device=0, subset=None) -> Matcher:
+def matcher_from_scene(scene, box=11, n_best=1, cost_comb=COMB_BEST_N, flags=0, seed=2024, device=0, subset=None, box_v=None) -> Matcher:
     """Convenience used by tests/bench: a Matcher loaded with a tsar_mvs_amd.synth.Scene."""
     m = Matcher(device)
-    m.set_params(default_params(box_hsize=box, box_vsize=box, n_best=n_best, cost_comb=cost_comb, depth_min=scene.depth_min,
+    m.set_params(default_params(box_hsize=box, box_vsize=box if box_v is None else box_v, n_best=n_best, cost_comb=cost_comb, depth_min=scene.depth_min,
                                 depth_max=scene.depth_max, flags=flags, seed=seed))
     m.set_views(scene.images, scene.K, scene.R, scene.t)
     if subset is not None:

@@ -152,6 +152,7 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          fast mode only; strict keeps the oracle's column order.
 //   bit 8: experiment (wrong results): the instruction mix of pairing two taps into one 16-byte gather
 //   bit 9: radius 5, with bits 3 and 6 — gathers of line t+1 issued before line t is blended (two register sets)
+//   bit 10: any window, 8-bit imagery — view_cost_lut (pm_core_lut.h) instead of this function; bits 11-13 = taps per chunk
 // BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread])
 template <int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const typename TileOf<QUAD>::type* tile, int tw, int own, const float* wts,
@@ -480,6 +481,8 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     return fmaxf(0.0f, fminf(TSAR_MAXCOST, 1.0f - covar / vrs));
 }
 
+#include "pm_core_lut.h"   // view_cost_lut: any window, weights from a shared table (variant bit 10; chunk length in bits 11-13)
+
 // pmCostMultiview_cu gipuma.cu:455-518: best-N combination over the selected views.  The NB
 // smallest costs are kept sorted in registers (sort_small :425-434 sorts all of them).
 template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
@@ -493,7 +496,9 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
     float cmin = __builtin_inff();
     for (int i = 0; i < num; i++) {
         const int vi = sc->sel[i];
-        float c = view_cost<HR, STRICT, QUAD, V, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        float c;
+        if constexpr ((V & 1024) != 0) c = view_cost_lut<STRICT, (V >> 11) & 7>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        else c = view_cost<HR, STRICT, QUAD, V, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;
         if (c <= cmin) { cmin = c; bv = vi; }   // last view attaining the minimum (gipuma.cu:506-510)
         float v = c;

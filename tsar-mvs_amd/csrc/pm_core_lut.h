@@ -1,0 +1,189 @@
+// pm_core_lut.h — the matching cost for ANY window (box 1..63, square or not) on 8-bit imagery: the production tap loop of
+// pm_core.h (view_cost, variant 250 / 122) is written for the scripts' box 11; every other box — the reference binary's own
+// default is 19 (algorithmparameters.h:25) — used to fall to a one-tap-at-a-time loop whose S hoisted weights per thread
+// (100 KiB of LDS per workgroup at box 19) left one wave per SIMD.  Included by pm_core.h.
+//
+// What differs from the box-11 loop:
+//   * weights.  exp(-sqrt(i^2 + j^2) / 50 - |r - centre| / 18) (gipuma.cu:268) takes its second argument from the integers
+//     0..255 on 8-bit imagery and its first from the few distinct tap distances of the window (14 at box 19), so the
+//     workgroup keeps ONE table [distance class][0..255] in LDS — evaluated with the same expression, so the values are the
+//     oracle's bit for bit — and a tap looks its weight up with |r - centre| as the index.  LDS per workgroup: 15 KiB at box 19
+//     instead of 100, occupancy is bounded by registers again (four waves per SIMD).  Cost: three VALU instructions and one
+//     LDS gather per tap.
+//   * shape.  A line of the window (a row in fast mode, a column — the oracle's summation order — in strict mode) is walked
+//     in chunks of CH = 4, 5 or 6 taps, each chunk in the three phases of the box-11 loop (positions, gathers, blend), CH
+//     chosen by the host so that the line length rounds up with the fewest padding slots.  A padding slot repeats the line's
+//     last tap with a weight from the table's all-zero row: it adds +0 to the three sums, so the result does not depend on CH.
+#pragma once
+
+// The table: (classes + 1) rows of 256 floats at the start of the workgroup's LDS.
+template <int BLK>
+DEVFN void build_weight_lut(const DevScene* __restrict__ sc, float* lut) {
+    const int nc = sc->lut_classes;
+    for (int k = threadIdx.x; k < (nc + 1) * 256; k += BLK) {
+        const int cls = k >> 8;
+        float wt = 0.0f;
+        if (cls < nc) {
+            const float sd = sqrtf((float)sc->lut_d2[cls]);
+            const float cd = (float)(k & 255);
+            wt = tsar_expf(-sd / 50.0f - cd / 18.0f);      // the expression of hoist_reference (pm_core.h), gipuma.cu:268
+        }
+        lut[k] = wt;
+    }
+}
+
+DEVFN float lut_weight(const float* lut, uint32_t row_bytes, float r, float cen) {
+    const int idx = (int)fabsf(r - cen);                    // integer-valued: texels are 0..255
+    return *(const float*)((const char*)lut + row_bytes + (uint32_t)idx * 4u);
+}
+
+// hoist_reference (pm_core.h) with the weights read from the table; the oracle's tap order (columns).
+DEVFN PixelRef hoist_reference_lut(const DevScene* __restrict__ sc, const unsigned short* tile, int tw, int own, const float* lut) {
+    const int hr = sc->hrad, vr = sc->vrad;
+    const bool rowm = sc->lut_row_major != 0;
+    const float cen = tile_value(tile[own]);
+    float sum_ref = 0.f, sum_ref_ref = 0.f, wsum = 0.f;
+    for (int ii = 0; ii <= hr; ii++) {
+        const int i = 2 * ii - hr;
+        for (int jj = 0; jj <= vr; jj++) {
+            const int j = 2 * jj - vr;
+            const float r = tile_value(tile[own + j * tw + i]);
+            const float wt = lut_weight(lut, rowm ? sc->tap_row[jj][ii] : sc->tap_row[ii][jj], r, cen);
+            const float wr = wt * r;
+            sum_ref += wr;
+            sum_ref_ref = fma_(wr, r, sum_ref_ref);
+            wsum += wt;
+        }
+    }
+    PixelRef pr;
+    pr.inv_wsum = 1.0f / wsum;
+    sum_ref *= pr.inv_wsum;
+    sum_ref_ref *= pr.inv_wsum;
+    pr.mean_ref = sum_ref;
+    pr.var_ref = sum_ref_ref - sum_ref * sum_ref;
+    pr.textured = !(pr.var_ref < 1e-5f);
+    return pr;
+}
+
+// pmCost (gipuma.cu:229-298) for one source view, any window, 8-bit quad textures.
+template <bool STRICT, int CH>
+DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, const unsigned short* tile, int tw, int own, const float* lut,
+                          const PixelRef& pr, int x, int y, const float4& n4) {
+    constexpr bool ROW = !STRICT;                           // fast mode walks window rows (see pm_core.h, variant bit 7)
+    const int hr = sc->hrad, vr = sc->vrad;
+    const int rt = ROW ? hr : vr, rl = ROW ? vr : hr;       // radius along / across the lines
+    const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
+    float H[9];
+    if (STRICT) plane_homography(sc->ref, vw, n4, H);
+    else plane_homography_fast(sc->ref, vw, n4, H);
+    // clamp-free loop when the four corner taps of every active lane land inside the source image with Z > 0 and a pixel of
+    // margin (pm_core.h, variant bit 4): wave-uniform, identical results
+    bool inside = true;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float xi = (float)(x + ((c & 1) ? hr : -hr)), yj = (float)(y + ((c & 2) ? vr : -vr));
+        const float X = fma_(H[1], yj, fma_(H[0], xi, H[2])), Y = fma_(H[4], yj, fma_(H[3], xi, H[5])), Z = fma_(H[7], yj, fma_(H[6], xi, H[8]));
+        const float rz = __builtin_amdgcn_rcpf(Z);
+        const float u = X * rz, v = Y * rz;
+        inside = inside && Z > 0.0f && u >= 1.0f && u <= (float)(w - 2) && v >= 1.0f && v <= (float)(h - 2);
+    }
+    const bool need_clamp = !__all(inside);
+    // quad-texture base with the border offset folded in, pinned in an SGPR pair for the whole view (pm_core.h, variant bit 6):
+    // offsets are unsigned from entry (1, 1), so positions are clamped to [0, w - 1] x [0, h - 1] — the same samples, bit for
+    // bit, as the oracle's clamp to [-1, w] (edge replication)
+    const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)((qp + 1) << 2);
+    uint32_t qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qa), qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32));
+    asm volatile("" : "+s"(qb_lo), "+s"(qb_hi));
+    const float cen = tile_value(tile[own]);
+    const float fa = (float)(ROW ? x : y), fl = (float)(ROW ? y : x);
+    const float uhi = (float)(w - 1), vhi = (float)(h - 1);
+    const int tstride = ROW ? 2 : 2 * tw;                   // tile entries between consecutive taps of a line
+    float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
+    auto chunk = [&](const unsigned short* trow, const uint32_t* rows, int c0, float bx, float by, float bz, auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
+        float r[CH], ax[CH], ay[CH], wv[CH];
+        uint32_t q[CH];
+#pragma unroll
+        for (int jj = 0; jj < CH; jj++) r[jj] = tile_value(trow[min(c0 + jj, rt) * tstride]);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int jj = 0; jj < CH; jj++) {                   // phase 1: tap positions -> byte offsets; phase 2: gathers
+            const float yj = fa + (float)(2 * min(c0 + jj, rt) - rt);
+            const float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
+            float u, v;
+            int iu, iv;
+            if (STRICT) {                                   // the oracle's operations: IEEE divides, min/max clamp, floor / subtract
+                u = X / Z;
+                v = Y / Z;
+                if (CLAMP) {
+                    u = fminf(fmaxf(u, 0.0f), uhi);
+                    v = fminf(fmaxf(v, 0.0f), vhi);
+                }
+                const float fu = floorf(u), fv = floorf(v);
+                ax[jj] = u - fu;
+                ay[jj] = v - fv;
+                iu = (int)fu;
+                iv = (int)fv;
+            } else {
+                const float rz = __builtin_amdgcn_rcpf(Z);
+                u = X * rz;
+                v = Y * rz;
+                if (CLAMP) {
+                    u = __builtin_amdgcn_fmed3f(u, 0.0f, uhi);
+                    v = __builtin_amdgcn_fmed3f(v, 0.0f, vhi);
+                }
+                ax[jj] = __builtin_amdgcn_fractf(u);
+                ay[jj] = __builtin_amdgcn_fractf(v);
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
+            }
+            int lin;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
+            q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + ((uint32_t)lin << 2));
+        }
+#pragma unroll
+        for (int jj = 0; jj < CH; jj++) wv[jj] = lut_weight(lut, rows[c0 + jj], r[jj], cen);
+        __builtin_amdgcn_sched_barrier(0);                  // nothing of phase 3 may move above the last gather
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < CH; jj++) {                   // phase 3: unpack, blend, accumulate
+            float t00, t10, t01, t11;
+            asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
+            asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
+            asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
+            asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q[jj]));
+            const float top = fma_(ax[jj], t10 - t00, t00);
+            const float bot = fma_(ax[jj], t11 - t01, t01);
+            const float s = fma_(ay[jj], bot - top, top);
+            const float wt = wv[jj];
+            const float ws = wt * s;
+            sum_src += ws;
+            sum_src_src = fma_(ws, s, sum_src_src);
+            if (STRICT) sum_ref_src = fma_(wt * r[jj], s, sum_ref_src);   // (w r) s, the oracle's order
+            else sum_ref_src = fma_(ws, r[jj], sum_ref_src);              // (w s) r: one multiply fewer per tap
+        }
+    };
+    auto lines = [&](auto clamp_tag) {
+#pragma unroll 1
+        for (int l = 0; l <= rl; l++) {
+            const int ol = 2 * l - rl;
+            const float xi = fl + (float)ol;
+            const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
+            const unsigned short* trow = tile + own + (ROW ? ol * tw - rt : ol - rt * tw);
+            const uint32_t* rows = sc->tap_row[l];
+#pragma unroll 1
+            for (int c0 = 0; c0 <= rt; c0 += CH) chunk(trow, rows, c0, bx, by, bz, clamp_tag);
+        }
+    };
+    if (need_clamp) lines(std::true_type());
+    else lines(std::false_type());
+    sum_src *= pr.inv_wsum;
+    sum_src_src *= pr.inv_wsum;
+    sum_ref_src *= pr.inv_wsum;
+    const float var_src = sum_src_src - sum_src * sum_src;
+    if (var_src < 1e-5f) return TSAR_MAXCOST;
+    const float covar = sum_ref_src - pr.mean_ref * sum_src;
+    const float vrs = sqrtf(pr.var_ref * var_src);
+    return fmaxf(0.0f, fminf(TSAR_MAXCOST, 1.0f - covar / vrs));
+}

@@ -179,6 +179,26 @@ static void fill_scene_params(tsar_ctx* ctx) {
     sc.flags = p.flags;
     sc.seed_lo = (uint32_t)p.seed;
     sc.seed_hi = (uint32_t)(p.seed >> 32);
+    // weight table of the general-window tap loop (tsar_dev.h DevScene::tap_row): distance classes of the window's taps, and
+    // per (line, tap of the line) the row of its class.  Fast mode walks window rows, strict mode the oracle's columns.
+    sc.lut_row_major = (p.flags & TSAR_FLAG_STRICT_DIV) ? 0 : 1;
+    std::vector<int> d2;
+    for (int i = -sc.hrad; i <= sc.hrad; i += 2)
+        for (int j = -sc.vrad; j <= sc.vrad; j += 2) d2.push_back(i * i + j * j);
+    std::sort(d2.begin(), d2.end());
+    d2.erase(std::unique(d2.begin(), d2.end()), d2.end());
+    sc.lut_classes = (int)d2.size() <= TSAR_LUT_MAX_CLASSES ? (int)d2.size() : 0;
+    for (int k = 0; k < sc.lut_classes; k++) sc.lut_d2[k] = d2[k];
+    const int rl = sc.lut_row_major ? sc.vrad : sc.hrad, rt = sc.lut_row_major ? sc.hrad : sc.vrad;   // radius across / along the lines
+    for (int l = 0; l < TSAR_LUT_LINES; l++)
+        for (int t = 0; t < TSAR_LUT_TAPS; t++) {
+            int cls = sc.lut_classes;                                     // the zero row: slots beyond the end of a line
+            if (sc.lut_classes && l <= rl && t <= rt) {
+                const int a = 2 * l - rl, b = 2 * t - rt;
+                cls = (int)(std::lower_bound(d2.begin(), d2.end(), a * a + b * b) - d2.begin());
+            }
+            sc.tap_row[l][t] = (uint32_t)cls * 1024u;
+        }
 }
 static int upload_scene(tsar_ctx* ctx) {
     if (!ctx->dscene) TRY(dev_alloc(ctx, &ctx->dscene, 1));
@@ -282,12 +302,6 @@ extern "C" int tsar_set_params(tsar_ctx* ctx, const tsar_params* p) {
     if (!p) return fail(ctx, TSAR_ERR_INVALID, "params is NULL");
     if (p->box_hsize < 1 || p->box_vsize < 1 || p->box_hsize > 63 || p->box_vsize > 63) return fail(ctx, TSAR_ERR_INVALID, "box size must be in 1..63");
     if (p->n_best < 1 || p->n_best > TSAR_MAX_SELECTED) return fail(ctx, TSAR_ERR_INVALID, "n_best must be in 1..32 (the reference's costVector holds 32 views, gipuma.cu:467)");
-    {
-        // the hoisted bilateral weights live in LDS, (hrad+1)(vrad+1) taps x 256 threads x 4 B, beside the reference window
-        const int hr = (p->box_hsize - 1) / 2, vr = (p->box_vsize - 1) / 2;
-        const size_t lds = (size_t)(hr + 1) * (vr + 1) * 1024 + (size_t)(32 + 2 * hr) * (16 + 2 * vr) * 4 + 16;
-        if (lds > 160 * 1024) return fail(ctx, TSAR_ERR_INVALID, "box too large: its weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
-    }
     if (p->cost_comb < TSAR_COMB_ALL || p->cost_comb > TSAR_COMB_GOOD) return fail(ctx, TSAR_ERR_INVALID, "cost_comb must be one of TSAR_COMB_ALL / BEST_N / ANGLE / GOOD");
     if (!(p->depth_min > 0.f) || !(p->depth_max > p->depth_min)) return fail(ctx, TSAR_ERR_INVALID, "need 0 < depth_min < depth_max");
     if (!(p->cam_scale > 0.f)) return fail(ctx, TSAR_ERR_INVALID, "cam_scale must be > 0");
@@ -344,6 +358,13 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
         for (auto& q : ctx->quad) dev_free(q);
     derive_cameras(ctx, cams);
     fill_scene_params(ctx);
+    if (!lut_path_applies(ctx)) {
+        // float imagery (and the 8-bit-filter mode) keeps the hoisted bilateral weights per thread in LDS, (hrad+1)(vrad+1) taps x
+        // 256 threads x 4 B beside the reference window; 8-bit imagery shares one table per workgroup (pm_core_lut.h): any box
+        const size_t lds = (size_t)(sc.hrad + 1) * (sc.vrad + 1) * 1024 + (size_t)(32 + 2 * sc.hrad) * (16 + 2 * sc.vrad) * 4 + 16;
+        if (lds > 160 * 1024)
+            return fail(ctx, TSAR_ERR_INVALID, "box too large for images that are not 8-bit (or with TSAR_FLAG_TEX_FILTER_8BIT): the per-thread weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
+    }
     sc.n_sel = std::min(n_views - 1, TSAR_MAX_SELECTED);   // default subset: the first 32 source views at most (tsar_set_view_subset picks others)
     for (int i = 0; i < sc.n_sel; i++) sc.sel[i] = i + 1;
     // state planes (LineState::resize linestate.h:71-110)

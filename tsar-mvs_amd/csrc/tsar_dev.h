@@ -3,12 +3,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
 
 #include "../../include/tsar.h"
 
+#define TSAR_LUT_LINES 32         // box <= 63: at most 32 lines of at most 32 taps
+#define TSAR_LUT_TAPS 40          // 32 rounded up to whole chunks of 4 / 5 / 6 taps, plus slack
+#define TSAR_LUT_MAX_CLASSES 144  // (rows + 1) KiB of LDS: what fits beside the reference window in 160 KiB
 #define TSAR_MAX_SELECTED 32   // views scored per hypothesis: the reference's costVector[32] (gipuma.cu:467-468)
 
 // One source view as the kernels read it: pose relative to the reference camera (ref = K[I|0]),
@@ -53,6 +57,13 @@ struct DevScene {
     DevRef ref;
     int sel[TSAR_MAX_VIEWS];   // view indices in pair.txt order
     DevView view[TSAR_MAX_VIEWS];
+    // Shared weight table of the general-window tap loop (pm_core.h view_cost_lut; 8-bit imagery): the bilateral weight
+    // exp(-sqrt(i^2 + j^2) / 50 - |r - centre| / 18) of a tap depends on its distance class (the distinct i^2 + j^2 of the
+    // window) and on an integer 0..255, so a workgroup keeps one 256-entry row per class in LDS instead of S weights per thread.
+    int lut_classes;                               // rows of the table; row lut_classes is all zero (padding taps of a line's last chunk)
+    int lut_row_major;                             // 1: lines of the walk are window rows (fast mode), 0: window columns (the oracle's order)
+    int lut_d2[TSAR_LUT_MAX_CLASSES];              // i^2 + j^2 per class
+    uint32_t tap_row[TSAR_LUT_LINES][TSAR_LUT_TAPS];   // [line][tap of the line] -> byte offset of the tap's row in the table
 };
 
 // State planes of one ping-pong buffer (linestate.h:12-13).
@@ -125,6 +136,22 @@ int launch_pm_init(tsar_ctx* ctx);
 bool probe_d16_hi_zeroes(tsar_ctx* ctx);   // pm_sweep.hip
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                     uint32_t stream_id, int do_prop, int do_refine);
+int launch_pm_sweep_lut(tsar_ctx* ctx, int need, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
+                        int do_prop, int do_refine);       // pm_sweep_lut.hip
+int launch_pm_full_lut(tsar_ctx* ctx, int need, bool init, const float4* planes, float* c, float4* n, int32_t* bv, float* rt);   // pm_init_lut.hip
+int lut_chunk_taps(int taps_per_line);
+// the general-window tap loop serves 8-bit imagery (quad textures) with exact-fp32 filtering whose window has few enough
+// distance classes for the LDS table; TSAR_LUT=0 switches it off (the one-tap-at-a-time loop then runs), TSAR_LUT=2 also sends
+// the box-11 / two-best-views configuration through it instead of its own tap loop: A/B measurements
+static inline bool lut_path_forced() {
+    static const bool forced = getenv("TSAR_LUT") && getenv("TSAR_LUT")[0] == '2';
+    return forced;
+}
+static inline bool lut_path_applies(const tsar_ctx* ctx) {
+    static const bool off = getenv("TSAR_LUT") && getenv("TSAR_LUT")[0] == '0';
+    const DevScene& hs = ctx->hscene;
+    return !off && hs.use_quad && hs.lut_classes > 0 && !(hs.flags & TSAR_FLAG_TEX_FILTER_8BIT);
+}
 int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                         int do_prop, int do_refine, int* launched);
 int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio);
