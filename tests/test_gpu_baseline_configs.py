@@ -191,7 +191,7 @@ def test_lds_patch_sweep_variant_bit_exact(monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("box,n_best,n_src", [(19, 2, 3), (7, 1, 3), (11, 1, 1), (11, 3, 5), (5, 1, 2), (9, 1, 2), (15, 4, 5), (27, 1, 2), ((13, 7), 2, 3)])
+@pytest.mark.parametrize("box,n_best,n_src", [(19, 2, 3), (7, 1, 3), (11, 1, 1), (11, 3, 5), (5, 1, 2), (9, 1, 2), (15, 4, 5), (27, 1, 2), ((13, 7), 2, 3), (11, 4, 5), (11, 5, 5), (19, 6, 6), (7, 5, 5)])
 def test_other_windows_and_view_counts_bit_exact(box, n_best, n_src):
     """the general-window kernels (pm_core_lut.h: runtime radius — the reference's default box is 19 = 100 taps —, weights from
     the shared table, chunked lines), best-N lists longer than two, and a single source view (ratio is defined as 0 there,

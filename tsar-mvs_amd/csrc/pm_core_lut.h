@@ -41,6 +41,7 @@ DEVFN float lut_weight(const float* lut, uint32_t row_bytes, float r, float cen)
 DEVFN PixelRef hoist_reference_lut(const DevScene* __restrict__ sc, const unsigned short* tile, int tw, int own, const float* lut) {
     const int hr = sc->hrad, vr = sc->vrad;
     const bool rowm = sc->lut_row_major != 0;
+    const int pt = sc->lut_pad_taps;
     const float cen = tile_value(tile[own]);
     float sum_ref = 0.f, sum_ref_ref = 0.f, wsum = 0.f;
     for (int ii = 0; ii <= hr; ii++) {
@@ -48,7 +49,7 @@ DEVFN PixelRef hoist_reference_lut(const DevScene* __restrict__ sc, const unsign
         for (int jj = 0; jj <= vr; jj++) {
             const int j = 2 * jj - vr;
             const float r = tile_value(tile[own + j * tw + i]);
-            const float wt = lut_weight(lut, rowm ? sc->tap_row[jj][ii] : sc->tap_row[ii][jj], r, cen);
+            const float wt = lut_weight(lut, rowm ? sc->tap_row[jj * pt + ii] : sc->tap_row[ii * pt + jj], r, cen);
             const float wr = wt * r;
             sum_ref += wr;
             sum_ref_ref = fma_(wr, r, sum_ref_ref);
@@ -66,6 +67,17 @@ DEVFN PixelRef hoist_reference_lut(const DevScene* __restrict__ sc, const unsign
 }
 
 // pmCost (gipuma.cu:229-298) for one source view, any window, 8-bit quad textures.
+// Fast mode (rows): the window of the workgroup is staged with one extra row (LUT_TILE_PAD_ROWS), so that the padding slots of a
+// row's last chunk may read the texels that follow the row (finite values, zero weight) with immediate offsets.
+#define LUT_TILE_PAD_ROWS 1
+// The chunk's D16 window loads (issued by asm, invisible to the compiler's counters) have returned.  `after`: the byte offset of
+// the chunk's last gather — an input, so that the wait cannot be scheduled above the tap-position arithmetic.
+template <int CH>
+DEVFN void lut_wait_lds(float (&r)[CH], uint32_t after) {
+    if constexpr (CH == 4) asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(after));
+    else if constexpr (CH == 5) asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "v"(after));
+    else asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "v"(after));
+}
 template <bool STRICT, int CH>
 DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, const unsigned short* tile, int tw, int own, const float* lut,
                           const PixelRef& pr, int x, int y, const float4& n4) {
@@ -77,11 +89,13 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     if (STRICT) plane_homography(sc->ref, vw, n4, H);
     else plane_homography_fast(sc->ref, vw, n4, H);
     // clamp-free loop when the four corner taps of every active lane land inside the source image with Z > 0 and a pixel of
-    // margin (pm_core.h, variant bit 4): wave-uniform, identical results
+    // margin (pm_core.h, variant bit 4): wave-uniform, identical results.  In fast mode the padding slots of a row's last chunk
+    // are sampled where they fall, beyond the window's right edge: the corners include them.
+    const int xr = ROW ? 2 * (sc->lut_pad_taps - 1) - hr : hr;
     bool inside = true;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const float xi = (float)(x + ((c & 1) ? hr : -hr)), yj = (float)(y + ((c & 2) ? vr : -vr));
+        const float xi = (float)(x + ((c & 1) ? xr : -hr)), yj = (float)(y + ((c & 2) ? vr : -vr));
         const float X = fma_(H[1], yj, fma_(H[0], xi, H[2])), Y = fma_(H[4], yj, fma_(H[3], xi, H[5])), Z = fma_(H[7], yj, fma_(H[6], xi, H[8]));
         const float rz = __builtin_amdgcn_rcpf(Z);
         const float u = X * rz, v = Y * rz;
@@ -97,18 +111,28 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     const float cen = tile_value(tile[own]);
     const float fa = (float)(ROW ? x : y), fl = (float)(ROW ? y : x);
     const float uhi = (float)(w - 1), vhi = (float)(h - 1);
-    const int tstride = ROW ? 2 : 2 * tw;                   // tile entries between consecutive taps of a line
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
-    auto chunk = [&](const unsigned short* trow, const uint32_t* rows, int c0, float bx, float by, float bz, auto clamp_tag) {
+    // rows: the table rows of this chunk's taps (scalars, loaded while the previous chunk ran)
+    auto chunk = [&](const unsigned short* trow, const uint32_t (&rows)[CH], int c0, float bx, float by, float bz, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         float r[CH], ax[CH], ay[CH], wv[CH];
-        uint32_t q[CH];
+        uint32_t q[CH], off_last = 0;
+        float yj0 = 0.f;
+        if constexpr (ROW) {
+            // the chunk's reference texels, each loaded into bits 31:16 of a register = its fp32 value (pm_core.h, variant bit 3);
+            // the wait for them is lut_wait_lds below, after the gathers are on their way
+            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(trow + 2 * c0);
 #pragma unroll
-        for (int jj = 0; jj < CH; jj++) r[jj] = tile_value(trow[min(c0 + jj, rt) * tstride]);
+            for (int jj = 0; jj < CH; jj++) asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(r[jj]) : "v"(a0), "n"(jj * 4), "v"(bz));
+            yj0 = fa + (float)(2 * c0 - rt);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < CH; jj++) r[jj] = tile_value(trow[min(c0 + jj, rt) * 2 * tw]);
+        }
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int jj = 0; jj < CH; jj++) {                   // phase 1: tap positions -> byte offsets; phase 2: gathers
-            const float yj = fa + (float)(2 * min(c0 + jj, rt) - rt);
+            const float yj = ROW ? yj0 + (float)(2 * jj) : fa + (float)(2 * min(c0 + jj, rt) - rt);
             const float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
             float u, v;
             int iu, iv;
@@ -139,10 +163,12 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             }
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-            q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + ((uint32_t)lin << 2));
+            off_last = (uint32_t)lin << 2;
+            q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off_last);
         }
+        if constexpr (ROW) lut_wait_lds<CH>(r, off_last);
 #pragma unroll
-        for (int jj = 0; jj < CH; jj++) wv[jj] = lut_weight(lut, rows[c0 + jj], r[jj], cen);
+        for (int jj = 0; jj < CH; jj++) wv[jj] = lut_weight(lut, rows[jj], r[jj], cen);
         __builtin_amdgcn_sched_barrier(0);                  // nothing of phase 3 may move above the last gather
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -165,15 +191,26 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
         }
     };
     auto lines = [&](auto clamp_tag) {
+        const uint32_t* rp = sc->tap_row;                   // walked linearly: chunks are consecutive in the table
+        uint32_t rows[CH];
+#pragma unroll
+        for (int jj = 0; jj < CH; jj++) rows[jj] = rp[jj];
 #pragma unroll 1
         for (int l = 0; l <= rl; l++) {
             const int ol = 2 * l - rl;
             const float xi = fl + (float)ol;
             const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
             const unsigned short* trow = tile + own + (ROW ? ol * tw - rt : ol - rt * tw);
-            const uint32_t* rows = sc->tap_row[l];
 #pragma unroll 1
-            for (int c0 = 0; c0 <= rt; c0 += CH) chunk(trow, rows, c0, bx, by, bz, clamp_tag);
+            for (int c0 = 0; c0 <= rt; c0 += CH) {
+                rp += CH;
+                uint32_t nxt[CH];                           // (the table has slack after its last chunk)
+#pragma unroll
+                for (int jj = 0; jj < CH; jj++) nxt[jj] = rp[jj];
+                chunk(trow, rows, c0, bx, by, bz, clamp_tag);
+#pragma unroll
+                for (int jj = 0; jj < CH; jj++) rows[jj] = nxt[jj];
+            }
         }
     };
     if (need_clamp) lines(std::true_type());

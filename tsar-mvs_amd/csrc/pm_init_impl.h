@@ -23,7 +23,7 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_full_kernel(const DevScene* __res
     int tix, tiy;
     strip_tile(t, tiles_x, n_tiles / tiles_x, strip_w, tix, tiy);
     const int ty0 = tiy * FULL_RH, tx0 = tix * PM_RW;
-    stage_ref_tile<FULL_RH, TileT>(sc, tile, tx0, ty0, hr, vr);
+    stage_ref_tile<FULL_RH, TileT>(sc, tile, tx0, ty0, hr, vr, LUTW ? LUT_TILE_PAD_ROWS : 0);
     __syncthreads();
     const int ly = threadIdx.x >> 5, lx = threadIdx.x & 31;
     const int x = tx0 + lx, y = ty0 + ly;
@@ -80,7 +80,7 @@ static int launch_full_t(tsar_ctx* ctx, const float4* planes, float* c, float4* 
     const DevScene& hs = ctx->hscene;
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + FULL_RH - 1) / FULL_RH;
     const int n_tiles = tiles_x * tiles_y;
-    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, FULL_RH + 2 * hs.vrad) +
+    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, FULL_RH + 2 * hs.vrad + ((V & 1024) ? LUT_TILE_PAD_ROWS : 0)) +
                        ((V & 1024) ? (size_t)(hs.lut_classes + 1) * 1024 : sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * PM_BLOCK);
     auto kern = pm_full_kernel<NB, HR, STRICT, QUAD, INIT, V>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

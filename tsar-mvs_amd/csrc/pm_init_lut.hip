@@ -20,7 +20,8 @@ static int launch_full_lut_ns(tsar_ctx* ctx, int ch, bool init, const float4* pl
 int launch_pm_full_lut(tsar_ctx* ctx, int need, bool init, const float4* planes, float* c, float4* n, int32_t* bv, float* rt) {
     const DevScene& hs = ctx->hscene;
     const bool strict = hs.flags & TSAR_FLAG_STRICT_DIV;
-    const int ch = lut_chunk_taps((hs.lut_row_major ? hs.hrad : hs.vrad) + 1);
+    const int ch = hs.lut_chunk;
     if (need <= 2) return strict ? launch_full_lut_ns<2, true>(ctx, ch, init, planes, c, n, bv, rt) : launch_full_lut_ns<2, false>(ctx, ch, init, planes, c, n, bv, rt);
+    if (need <= 4) return strict ? launch_full_lut_ns<4, true>(ctx, ch, init, planes, c, n, bv, rt) : launch_full_lut_ns<4, false>(ctx, ch, init, planes, c, n, bv, rt);
     return strict ? launch_full_lut_ns<32, true>(ctx, ch, init, planes, c, n, bv, rt) : launch_full_lut_ns<32, false>(ctx, ch, init, planes, c, n, bv, rt);
 }

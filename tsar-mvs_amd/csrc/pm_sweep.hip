@@ -83,8 +83,15 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             }
         }
     }
-    if (strict) return quad ? launch_sweep_t<NB, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
-    return quad ? launch_sweep_t<NB, HR, false, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, HR, false, false>(ctx, colour, a, b, c, sid, dp, dr);
+    // box 11 with three or four best views: the same tap loop, four-register selection (256-thread workgroups only)
+    if (quad && NB == 4 && HR == 5 && !(ctx->hscene.flags & TSAR_FLAG_TEX_FILTER_8BIT) && (ctx->variant == 250 || ctx->variant == 122)) {
+        if (strict) return launch_sweep_t<4, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+        return ctx->variant == 250 ? launch_sweep_t<4, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr)
+                                   : launch_sweep_t<4, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+    }
+    constexpr int NBG = NB == 4 ? 32 : NB;      // the one-tap-at-a-time kernels exist for 2 and 32 best views
+    if (strict) return quad ? launch_sweep_t<NBG, HR, true, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NBG, HR, true, false>(ctx, colour, a, b, c, sid, dp, dr);
+    return quad ? launch_sweep_t<NBG, HR, false, true>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NBG, HR, false, false>(ctx, colour, a, b, c, sid, dp, dr);
 }
 
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
@@ -101,7 +108,9 @@ int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const Pl
     const bool r5 = hs.hrad == 5 && hs.vrad == 5;
     // 8-bit imagery, any window but the box-11 / two-best-views configuration (which has its own tap loop): shared weight
     // table, chunked lines (pm_sweep_lut.hip)
-    if (lut_path_applies(ctx) && (!(r5 && need <= 2) || lut_path_forced())) return launch_pm_sweep_lut(ctx, need, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
+    const bool own_loop = r5 && need <= 4 && (need <= 2 || ctx->variant == 250 || ctx->variant == 122);
+    if (lut_path_applies(ctx) && (!own_loop || lut_path_forced())) return launch_pm_sweep_lut(ctx, need, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
+    if (need <= 4 && need > 2 && r5) return launch_sweep_nh<4, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     if (need <= 2) return r5 ? launch_sweep_nh<2, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
                              : launch_sweep_nh<2, 0>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     return r5 ? launch_sweep_nh<32, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)

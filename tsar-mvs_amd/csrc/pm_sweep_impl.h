@@ -125,7 +125,7 @@ __global__ __launch_bounds__(BLK, ((V & 512) ? 1024 / BLK : 1)) void pm_sweep_ke
     int tix, tiy;
     strip_tile(t, tiles_x, n_tiles / tiles_x, strip_w, tix, tiy);
     const int ty0 = tiy * SWEEP_RH, tx0 = tix * PM_RW;
-    stage_ref_tile<SWEEP_RH, TileT, BLK>(sc, tile, tx0, ty0, hr, vr);
+    stage_ref_tile<SWEEP_RH, TileT, BLK>(sc, tile, tx0, ty0, hr, vr, LUTW ? LUT_TILE_PAD_ROWS : 0);
     __syncthreads();
 
     const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
@@ -227,7 +227,7 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
     const int tiles_x = (hs.w + PM_RW - 1) / PM_RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
     const int n_tiles = tiles_x * tiles_y;
     static const size_t lds_pad = getenv("TSAR_LDS_PAD") ? (size_t)atoi(getenv("TSAR_LDS_PAD")) : 0;   // occupancy experiments: unused LDS per workgroup
-    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad) + lds_pad +
+    const size_t lds = tile_bytes<QUAD>(PM_RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad + ((V & 1024) ? LUT_TILE_PAD_ROWS : 0)) + lds_pad +
                        ((V & 1024) ? (size_t)(hs.lut_classes + 1) * 1024 : sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * BLK);
     auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD, V, BLK>;
     if (lds > 64 * 1024) TSAR_HIP_TRY(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

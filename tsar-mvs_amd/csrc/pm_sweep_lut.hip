@@ -23,15 +23,18 @@ static int launch_sweep_lut_ns(tsar_ctx* ctx, int ch, int colour, const PlaneBuf
     }
 }
 
-// need: how many best views enter the cost (<= 2: the two-register selection, else the general one)
+// need: how many best views enter the cost (<= 2 / <= 4: selection in two / four registers, else the general one)
 int launch_pm_sweep_lut(tsar_ctx* ctx, int need, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                         int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
     const bool strict = hs.flags & TSAR_FLAG_STRICT_DIV;
-    const int ch = lut_chunk_taps((hs.lut_row_major ? hs.hrad : hs.vrad) + 1);
+    const int ch = hs.lut_chunk;
     if (need <= 2)
         return strict ? launch_sweep_lut_ns<2, true>(ctx, ch, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
                       : launch_sweep_lut_ns<2, false>(ctx, ch, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
+    if (need <= 4)
+        return strict ? launch_sweep_lut_ns<4, true>(ctx, ch, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
+                      : launch_sweep_lut_ns<4, false>(ctx, ch, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     return strict ? launch_sweep_lut_ns<32, true>(ctx, ch, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
                   : launch_sweep_lut_ns<32, false>(ctx, ch, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
 }

@@ -190,14 +190,13 @@ static void fill_scene_params(tsar_ctx* ctx) {
     sc.lut_classes = (int)d2.size() <= TSAR_LUT_MAX_CLASSES ? (int)d2.size() : 0;
     for (int k = 0; k < sc.lut_classes; k++) sc.lut_d2[k] = d2[k];
     const int rl = sc.lut_row_major ? sc.vrad : sc.hrad, rt = sc.lut_row_major ? sc.hrad : sc.vrad;   // radius across / along the lines
-    for (int l = 0; l < TSAR_LUT_LINES; l++)
-        for (int t = 0; t < TSAR_LUT_TAPS; t++) {
-            int cls = sc.lut_classes;                                     // the zero row: slots beyond the end of a line
-            if (sc.lut_classes && l <= rl && t <= rt) {
-                const int a = 2 * l - rl, b = 2 * t - rt;
-                cls = (int)(std::lower_bound(d2.begin(), d2.end(), a * a + b * b) - d2.begin());
-            }
-            sc.tap_row[l][t] = (uint32_t)cls * 1024u;
+    sc.lut_chunk = lut_chunk_taps(rt + 1);
+    sc.lut_pad_taps = (rt + sc.lut_chunk) / sc.lut_chunk * sc.lut_chunk;
+    for (uint32_t& r : sc.tap_row) r = (uint32_t)sc.lut_classes * 1024u;      // the zero row: slots beyond the end of a line
+    for (int l = 0; l <= rl && sc.lut_classes; l++)
+        for (int t = 0; t <= rt; t++) {
+            const int a = 2 * l - rl, b = 2 * t - rt;
+            sc.tap_row[l * sc.lut_pad_taps + t] = 1024u * (uint32_t)(std::lower_bound(d2.begin(), d2.end(), a * a + b * b) - d2.begin());
         }
 }
 static int upload_scene(tsar_ctx* ctx) {

@@ -62,8 +62,11 @@ struct DevScene {
     // window) and on an integer 0..255, so a workgroup keeps one 256-entry row per class in LDS instead of S weights per thread.
     int lut_classes;                               // rows of the table; row lut_classes is all zero (padding taps of a line's last chunk)
     int lut_row_major;                             // 1: lines of the walk are window rows (fast mode), 0: window columns (the oracle's order)
+    int lut_chunk;                                 // taps per chunk of a line: 4, 5 or 6 (the fewest padding slots)
+    int lut_pad_taps;                              // taps per line rounded up to whole chunks: the stride of tap_row
     int lut_d2[TSAR_LUT_MAX_CLASSES];              // i^2 + j^2 per class
-    uint32_t tap_row[TSAR_LUT_LINES][TSAR_LUT_TAPS];   // [line][tap of the line] -> byte offset of the tap's row in the table
+    uint32_t tap_row[TSAR_LUT_LINES * TSAR_LUT_TAPS + 8];   // [line * lut_pad_taps + tap of the line] -> byte offset of the tap's row in the
+                                                   // table (padding slots -> the zero row); chunks are consecutive: a walk reads it linearly
 };
 
 // State planes of one ping-pong buffer (linestate.h:12-13).
