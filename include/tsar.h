@@ -119,7 +119,9 @@ typedef struct tsar_camera {
 /* Subset of the reference's AlgorithmParameters (algorithmparameters.h:54-88) that the GPU path
  * reads.  Zero-initialise, then tsar_default_params(). */
 typedef struct tsar_params {
-    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19) */
+    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19).  1..63; images that are not an 8-bit decode (and
+                             TSAR_FLAG_TEX_FILTER_8BIT): tsar_set_views refuses boxes whose per-thread weight table exceeds
+                             the LDS (largest square box 23) */
     int32_t box_vsize;
     int32_t n_best;       /* --n_best (scripts 1; default 2) */
     int32_t cost_comb;    /* --cost_comb: TSAR_COMB_* */

@@ -153,7 +153,10 @@ static inline bool lut_path_forced() {
 static inline bool lut_path_applies(const tsar_ctx* ctx) {
     static const bool off = getenv("TSAR_LUT") && getenv("TSAR_LUT")[0] == '0';
     const DevScene& hs = ctx->hscene;
-    return !off && hs.use_quad && hs.lut_classes > 0 && !(hs.flags & TSAR_FLAG_TEX_FILTER_8BIT);
+    // (its fast-mode loop loads window texels with ds_read_u16_d16_hi: only where tsar_create's probe found the register's
+    // other half zeroed — variant bit 3)
+    const bool d16_ok = (hs.flags & TSAR_FLAG_STRICT_DIV) || (ctx->variant & 8);
+    return !off && d16_ok && hs.use_quad && hs.lut_classes > 0 && !(hs.flags & TSAR_FLAG_TEX_FILTER_8BIT);
 }
 int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                         int do_prop, int do_refine, int* launched);
