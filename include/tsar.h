@@ -162,7 +162,10 @@ void tsar_default_params(tsar_params* p);
 int tsar_set_params(tsar_ctx* ctx, const tsar_params* p);
 /* views[0] is the reference view, views[1..n-1] the source views, in the order of the reference's
  * argv image list.  gray[i] points at w*h float32.  Cameras are re-origined so that the reference
- * camera is K[I|0] (cameraGeometryUtils.h:270-302).  Must follow tsar_set_params. */
+ * camera is K[I|0] (cameraGeometryUtils.h:270-302).  Must follow tsar_set_params.
+ * n_views = 1 (the reference view alone) is enough for the textureless-refinement operators (tsar_load_planes, weak-texture
+ * detection, region RANSAC, fill — none of them reads a source image); the matching entry points (tsar_pm_*, tsar_lrdiff)
+ * then return TSAR_ERR_STATE. */
 int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem,
                    const tsar_camera* cams);
 /* indices (1..n_views-1) of the source views used for matching, in pair.txt order; at most 32 (the reference's

@@ -66,6 +66,9 @@ static hipMemcpyKind out_kind(int mem) { return mem == TSAR_MEM_DEVICE ? hipMemc
     if (!(ctx)) return TSAR_ERR_INVALID; \
     if (hipSetDevice((ctx)->device) != hipSuccess) return fail(ctx, TSAR_ERR_HIP, "hipSetDevice failed")
 #define NEED_VIEWS(ctx) if (!(ctx)->have_views) return fail(ctx, TSAR_ERR_STATE, "tsar_set_views has not been called")
+// matching scores planes against source views; a context holding the reference view only serves the textureless-refinement
+// operators (load_planes, weak-texture detection, region RANSAC, fill)
+#define NEED_SOURCES(ctx) if ((ctx)->hscene.n_sel < 1) return fail(ctx, TSAR_ERR_STATE, "no source views: tsar_set_views was given the reference view only")
 #define NEED_STATE(ctx) if (!(ctx)->have_state) return fail(ctx, TSAR_ERR_STATE, "no plane state: call tsar_pm_init, tsar_load_planes or tsar_set_plane first")
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != TSAR_OK) return rc_; } while (0)
 
@@ -318,7 +321,7 @@ extern "C" int tsar_set_params(tsar_ctx* ctx, const tsar_params* p) {
 extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
     CHECK_CTX(ctx);
     if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
-    if (n_views < 2 || n_views > TSAR_MAX_VIEWS) return fail(ctx, TSAR_ERR_INVALID, "n_views must be in 2..TSAR_MAX_VIEWS");
+    if (n_views < 1 || n_views > TSAR_MAX_VIEWS) return fail(ctx, TSAR_ERR_INVALID, "n_views must be in 1..TSAR_MAX_VIEWS");
     if (w < 8 || h < 8 || (int64_t)w * h > (int64_t)1 << 28) return fail(ctx, TSAR_ERR_INVALID, "image size out of range");
     if (w + 2 >= (1 << 23) || h + 2 >= (1 << 23)) return fail(ctx, TSAR_ERR_INVALID, "image side too long for the 24-bit quad addressing (w + 2, h + 2 < 2^23)");
     if (!gray || !cams) return fail(ctx, TSAR_ERR_INVALID, "gray/cams is NULL");
@@ -404,6 +407,7 @@ extern "C" int tsar_set_view_subset(tsar_ctx* ctx, int n, const int32_t* view_id
 extern "C" int tsar_pm_init(tsar_ctx* ctx) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
+    NEED_SOURCES(ctx);
     TRY(launch_pm_init(ctx));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_state = true;
@@ -451,6 +455,7 @@ static int pm_sweeps(tsar_ctx* ctx, int n_sweeps, int first_colour, int do_prop,
 extern "C" int tsar_pm_iterate(tsar_ctx* ctx, int iters) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
+    NEED_SOURCES(ctx);
     NEED_STATE(ctx);
     if (iters < 0) return fail(ctx, TSAR_ERR_INVALID, "iters must be >= 0");
     TRY(pm_sweeps(ctx, 2 * iters, 0, 1, 1));   // black then red, gipuma.cu:1744-1754
@@ -464,6 +469,7 @@ extern "C" int tsar_pm_iterate(tsar_ctx* ctx, int iters) {
 extern "C" int tsar_pm_iterate_final(tsar_ctx* ctx, int iters, const float* text, int mem) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
+    NEED_SOURCES(ctx);
     NEED_STATE(ctx);
     if (iters < 0) return fail(ctx, TSAR_ERR_INVALID, "iters must be >= 0");
     if (!text) return fail(ctx, TSAR_ERR_INVALID, "text is NULL");
@@ -485,6 +491,7 @@ extern "C" int tsar_pm_iterate_final(tsar_ctx* ctx, int iters, const float* text
 extern "C" int tsar_pm_sweep(tsar_ctx* ctx, int colour, int do_prop, int do_refine) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
+    NEED_SOURCES(ctx);
     NEED_STATE(ctx);
     TRY(pm_sweeps(ctx, 1, colour & 1, do_prop, do_refine));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -500,6 +507,7 @@ extern "C" int tsar_set_sweep_counter(tsar_ctx* ctx, int n) {
 extern "C" int tsar_pm_cost_planes(tsar_ctx* ctx, const float* planes, int mem, float* cost_out, int32_t* beview_out, float* ratio_out) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
+    NEED_SOURCES(ctx);
     if (!planes || !cost_out) return fail(ctx, TSAR_ERR_INVALID, "planes/cost_out is NULL");
     const size_t np = (size_t)ctx->w * ctx->h;
     float4* dpl = nullptr;
@@ -650,6 +658,7 @@ extern "C" int tsar_getview(tsar_ctx* ctx) {
 extern "C" int tsar_lrdiff(tsar_ctx* ctx) {
     CHECK_CTX(ctx);
     NEED_STATE(ctx);
+    NEED_SOURCES(ctx);
     TRY(launch_lrdiff(ctx));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TSAR_OK;

@@ -34,6 +34,8 @@
 #include <memory>
 #include <mutex>
 #include <sstream>
+#include <unistd.h>
+
 #include <string>
 #include <thread>
 #include <vector>
@@ -45,7 +47,7 @@ struct Options {
     std::string images_folder, mslp_folder, krt_file, output_folder;
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
-    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false, tex8 = false;
+    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false, tex8 = false, timing = false;
     tsar_fusion_params fusion{};
     int gpus = 1, workers = 1;      // --all: worker threads per GPU; each overlaps its file output with the next view's kernels
     uint64_t seed = 0;
@@ -54,9 +56,11 @@ struct Options {
 
 #include "tsar_io.h"
 
-// Host buffers that cross the boundary (decoded images in, depth / normal maps out) are page-locked (tsar_host_alloc): the DMA
-// engine then reads and writes them directly instead of going through the runtime's bounce buffers (a 6048 x 4032 view's results:
-// 9 ms instead of 30).  Falls back to ordinary memory when page-locking fails.
+// The result buffers (depth / normal maps out) are page-locked (tsar_host_alloc): the DMA engine then writes them directly
+// instead of going through the runtime's bounce buffers (a 6048 x 4032 view's results: 9 ms instead of 30), and one set serves
+// every view of a worker.  Decoded images are NOT page-locked: each is uploaded once per GPU (DeviceImageCache), and
+// page-locking 97 MB costs ~25 ms — serialised inside the runtime — against the ~7 ms it would take off that one copy.
+// Falls back to ordinary memory when page-locking fails.
 template <class T>
 struct PinnedAllocator {
     typedef T value_type;
@@ -105,7 +109,7 @@ static void mkdirs(const std::string& path) {
 static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
-           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [--texture-filter-8bit] [-color_processing] [--display_outputs]\n"
+           "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [--texture-filter-8bit] [-color_processing] [--display_outputs] [--timing]\n"
            "       tsar_gipuma --all [--gpus=N] [--fuse [--num_consistent=N --reproj_error=PX --depth_diff=REL --angle=DEG --used_list=0|1]]\n"
            "                   -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
@@ -160,6 +164,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         else if (!strcmp(a, "-krt_file") && i + 1 < argc) o.krt_file = argv[++i];
         else if (!strcmp(a, "-output_folder") && i + 1 < argc) o.output_folder = argv[++i];
         else if (!strcmp(a, "-color_processing")) o.color = true;      // main.cpp:727,909
+        else if (!strcmp(a, "--timing")) o.timing = true;                     // wall time of each host-side step of a view, on stdout
         else if (!strcmp(a, "--display_outputs")) o.display_outputs = true;   // TSAR_normals.png + TSAR_model.ply (main.cpp:1800-1838)
         else if (!strcmp(a, "-no_display") || starts("--cost_gamma=") || starts("--min_angle=") || starts("--max_angle=") || starts("--cost_tau_color=") ||
                  starts("--cost_tau_gradient=") || starts("--cost_alpha=") || starts("--max_views=") || starts("--num_img_processed=")) {
@@ -172,7 +177,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
 
 // Decoded images shared by all views of a run (--all visits every image as a reference once and as a source ~N times).
 struct ImageCache {
-    struct Entry { PinnedFloats gray; int w = 0, h = 0; bool ok = false; };
+    struct Entry { std::vector<float> gray; int w = 0, h = 0; bool ok = false; };
     std::mutex mu;
     std::map<std::string, std::shared_ptr<Entry>> items;
     std::shared_ptr<Entry> get(const std::string& path) {
@@ -239,19 +244,61 @@ static bool write_view_files(const HostResult& r) {
 static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds,
                     DeviceResult* keep = nullptr, HostResult* reuse = nullptr, bool defer_write = false) {
     const auto t0 = std::chrono::steady_clock::now();
-    const int n = (int)names.size();
+    auto t_last = t0;
+    std::string steps;                                            // --timing: "step ms | step ms | ..."
+    auto stamp = [&](const char* what) {
+        if (!o.timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, "%s%s %.1f", steps.empty() ? "" : " | ", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        steps += buf;
+        t_last = now;
+    };
+    // The refinement modes never read a source image (load_planes, weak-texture detection, region RANSAC and fill work on the
+    // reference view and the plane maps): only the reference image is decoded and handed to the library there.
+    const bool tsar_mode = o.mode == "tsar", external = o.mode == "load" || tsar_mode;
+    const int n_all = (int)names.size(), n = external ? 1 : n_all;
+    const std::string out_dir = o.mslp_folder + "APD/" + stem8(names[0]) + "/";   // main.cpp:1462, 1813-1830
+    // Everything a process has to do before its first kernel runs side by side: the HIP context (~0.2 s in a fresh process), the
+    // decode of the 1 + N images (~45 ms each at ETH3D size), and — refinement modes — the external maps and weak.png (inflating
+    // a full-size PNG takes ~0.3 s).  In --all runs the context and the images are already there for every view but the first.
+    tsar_ctx** shared = reuse ? reuse->shared_ctx : nullptr;
+    tsar_ctx* ctx = shared ? *shared : nullptr;
+    std::future<int> creating;
+    if (!ctx) creating = std::async(std::launch::async, [&ctx, device]() { return tsar_create(device, &ctx); });
+    struct ExternalMaps { std::vector<float> depth, normal, scale; int dh = 0, dw = 0, dnb = 0, nh = 0, nw = 0, nnb = 0, mw = 0, mh = 0; bool depth_ok = false, normal_ok = false, mask_ok = false; } ext;
+    std::future<void> reading_maps, reading_mask;
+    if (external) reading_maps = std::async(std::launch::async, [&]() {
+        ext.depth_ok = read_dmb(out_dir + "depths_geom.dmb", ext.depth, ext.dh, ext.dw, ext.dnb);
+        ext.normal_ok = read_dmb(out_dir + "normals.dmb", ext.normal, ext.nh, ext.nw, ext.nnb);
+    });
+    if (tsar_mode) reading_mask = std::async(std::launch::async, [&]() { ext.mask_ok = read_reliable_mask(out_dir + "weak.png", ext.scale, ext.mw, ext.mh); });
     std::vector<std::shared_ptr<ImageCache::Entry>> gray(n);
+    {
+        std::vector<std::future<std::shared_ptr<ImageCache::Entry>>> decoding;
+        for (int i = 0; i < n; i++)
+            decoding.push_back(std::async(std::launch::async, [&o, &names, i]() { return g_images.get(o.images_folder + pnm_name(names[i], o.color ? ".ppm" : ".pgm")); }));
+        for (int i = 0; i < n; i++) gray[i] = decoding[i].get();
+    }
+    // (every helper thread started above is joined before any return below: they reference this frame)
+    const int create_rc = creating.valid() ? creating.get() : TSAR_OK;
+    if (reading_maps.valid()) reading_maps.get();
+    if (reading_mask.valid()) reading_mask.get();
+    if (create_rc != TSAR_OK) { fprintf(stderr, "tsar_create(device %d) failed: %d\n", device, create_rc); return create_rc; }
+    if (shared) *shared = ctx;
+    // a context is destroyed here only when this call owns it, or after a failure (the next view then starts from a fresh one)
+    auto drop_ctx = [&]() { tsar_destroy(ctx); if (shared) *shared = nullptr; };
+    auto fail = [&](const char* what) { fprintf(stderr, "%s: %s\n", what, tsar_last_error(ctx)); drop_ctx(); return -1; };
     std::vector<const float*> ptrs(n), dev_ptrs;
     std::vector<tsar_camera> cams(n);
     int w = 0, h = 0;
     float dmin = o.depth_min, dmax = o.depth_max;
     for (int i = 0; i < n; i++) {
         const std::string ip = o.images_folder + pnm_name(names[i], o.color ? ".ppm" : ".pgm");
-        gray[i] = g_images.get(ip);
-        if (!gray[i]->ok) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); return -1; }
+        if (!gray[i]->ok) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); drop_ctx(); return -1; }
         const int wi = gray[i]->w, hi = gray[i]->h;
         if (i == 0) { w = wi; h = hi; }
-        if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); return -1; }
+        if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); drop_ctx(); return -1; }
         ptrs[i] = gray[i]->gray.data();
         if (reuse && reuse->shared_ctx) {                         // --all: resident device copy (falls back to the host buffer)
             const float* d = g_device_images.get(device, ip, *gray[i]);
@@ -259,21 +306,13 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         }
         CamFile cf;
         const std::string cp = o.mslp_folder + "cams/" + stem8(names[i]) + "_cam.txt";
-        if (!read_cam(cp, cf)) { fprintf(stderr, "cannot read camera %s\n", cp.c_str()); return -1; }
+        if (!read_cam(cp, cf)) { fprintf(stderr, "cannot read camera %s\n", cp.c_str()); drop_ctx(); return -1; }
         cams[i] = cf.cam;
         if (i == 0) {   // depth range of the reference view (fileIoUtils.h:150-153) unless given on the command line
             if (dmin <= 0) dmin = cf.depth_min;
             if (dmax <= 0) dmax = cf.depth_max;
         }
     }
-    tsar_ctx** shared = reuse ? reuse->shared_ctx : nullptr;
-    tsar_ctx* ctx = shared ? *shared : nullptr;
-    int rc = ctx ? TSAR_OK : tsar_create(device, &ctx);
-    if (rc != TSAR_OK) { fprintf(stderr, "tsar_create(device %d) failed: %d\n", device, rc); return rc; }
-    if (shared) *shared = ctx;
-    // a context is destroyed here only when this call owns it, or after a failure (the next view then starts from a fresh one)
-    auto drop_ctx = [&]() { tsar_destroy(ctx); if (shared) *shared = nullptr; };
-    auto fail = [&](const char* what) { fprintf(stderr, "%s: %s\n", what, tsar_last_error(ctx)); drop_ctx(); return -1; };
     tsar_params p;
     tsar_default_params(&p);
     p.box_hsize = p.box_vsize = o.blocksize;
@@ -283,48 +322,55 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0) |
               (o.tex8 ? TSAR_FLAG_TEX_FILTER_8BIT : 0);
     if (tsar_set_params(ctx, &p) != TSAR_OK) return fail("tsar_set_params");
+    stamp(external ? "context + reference image + external maps + weak.png (concurrent)" : "context + images + cameras (concurrent)");
     const bool resident = (int)dev_ptrs.size() == n;
     if (tsar_set_views(ctx, n, w, h, resident ? dev_ptrs.data() : ptrs.data(), resident ? TSAR_MEM_DEVICE : TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
-    if (!subset_slots.empty()) {
+    if (!subset_slots.empty() && !external) {
         std::vector<int32_t> s(subset_slots.begin(), subset_slots.end());
         if (tsar_set_view_subset(ctx, (int)s.size(), s.data()) != TSAR_OK) return fail("tsar_set_view_subset");
     }
-    const std::string out_dir = o.mslp_folder + "APD/" + stem8(names[0]) + "/";   // main.cpp:1462, 1813-1830
+    stamp("set_views");
     mkdirs(out_dir);
     const size_t np = (size_t)w * h;
-    const bool tsar_mode = o.mode == "tsar";
-    if (o.mode == "load" || tsar_mode) {
-        std::vector<float> d, nrm;
-        int hh, ww, nb;
-        if (!read_dmb(out_dir + "depths_geom.dmb", d, hh, ww, nb) || hh != h || ww != w || nb != 1) { fprintf(stderr, "cannot read %sdepths_geom.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
-        if (!read_dmb(out_dir + "normals.dmb", nrm, hh, ww, nb) || hh != h || ww != w || nb != 3) { fprintf(stderr, "cannot read %snormals.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
-        if (tsar_load_planes(ctx, d.data(), nrm.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_load_planes");
+    // page-locking the result buffers of a one-view process (0.39 GB at ETH3D size, ~0.1 s) happens beside the kernels
+    HostResult local;
+    HostResult& hr = reuse ? *reuse : local;
+    std::future<void> sizing;
+    if (hr.depth.size() != np) sizing = std::async(std::launch::async, [&hr, np]() { hr.depth.resize(np); hr.normal.resize(3 * np); });
+    struct JoinSizing { std::future<void>& f; ~JoinSizing() { if (f.valid()) f.get(); } } join_sizing{sizing};   // on every return path
+    if (external) {
+        if (!ext.depth_ok || ext.dh != h || ext.dw != w || ext.dnb != 1) { fprintf(stderr, "cannot read %sdepths_geom.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
+        if (!ext.normal_ok || ext.nh != h || ext.nw != w || ext.nnb != 3) { fprintf(stderr, "cannot read %snormals.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
+        if (tsar_load_planes(ctx, ext.depth.data(), ext.normal.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_load_planes");
+        stamp("load_planes");
     } else {
         if (tsar_pm_init(ctx) != TSAR_OK) return fail("tsar_pm_init");
         if (tsar_pm_iterate(ctx, o.iterations) != TSAR_OK) return fail("tsar_pm_iterate");
+        stamp("pm_init + pm_iterate");
     }
     if (tsar_mode) {
         // the reference's live path, runGipuma main.cpp:1493-1783: external planes (above: firstcuda) -> reliability mask
         // from weak.png -> weak-texture regions of the reference image (texture(), main.cpp:214-596) -> sliccuda
         // (gipuma_getview) -> per-region plane RANSAC (:1520-1730) -> fakecuda -> fillcuda
-        std::vector<float> scale;
-        int mw = 0, mh = 0;
-        if (!read_reliable_mask(out_dir + "weak.png", scale, mw, mh) || mw != w || mh != h) { fprintf(stderr, "cannot read %sweak.png (8-bit PNG of the image size)\n", out_dir.c_str()); drop_ctx(); return -1; }
-        if (tsar_set_reliable_mask(ctx, scale.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_set_reliable_mask");
+        if (!ext.mask_ok || ext.mw != w || ext.mh != h) { fprintf(stderr, "cannot read %sweak.png (8-bit PNG of the image size)\n", out_dir.c_str()); drop_ctx(); return -1; }
+        if (tsar_set_reliable_mask(ctx, ext.scale.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_set_reliable_mask");
+        stamp("set_reliable_mask");
         int n_regions = 0;
         if (tsar_detect_weak_texture(ctx, nullptr, TSAR_MEM_HOST, &n_regions, nullptr, nullptr, 0) != TSAR_OK) return fail("tsar_detect_weak_texture");
+        stamp("detect_weak_texture");
         if (tsar_getview(ctx) != TSAR_OK) return fail("tsar_getview");
         std::vector<float> planes((size_t)4 * (n_regions > 0 ? n_regions : 1)), ratio((size_t)(n_regions > 0 ? n_regions : 1));
         if (tsar_ransac_regions(ctx, planes.data(), ratio.data()) != TSAR_OK) return fail("tsar_ransac_regions");
+        stamp("getview + ransac_regions");
         if (tsar_fake_depth(ctx, nullptr, TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_fake_depth");
         if (tsar_fill_textureless(ctx) != TSAR_OK) return fail("tsar_fill_textureless");
+        stamp("fake_depth + fill_textureless");
         printf("view %08d: %d regions labelled, textureless ones refitted and filled\n", ref_id, n_regions);
     } else if (tsar_compute_disp(ctx) != TSAR_OK) return fail("tsar_compute_disp");
-    HostResult local;
-    HostResult& hr = reuse ? *reuse : local;
-    if (hr.depth.size() != np) { hr.depth.resize(np); hr.normal.resize(3 * np); }
+    if (sizing.valid()) sizing.get();
     PinnedFloats &depth = hr.depth, &normal = hr.normal;
     if (tsar_get_result(ctx, depth.data(), normal.data(), nullptr, nullptr, TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_get_result");
+    stamp("get_result");
     if (keep) {   // the same maps stay on this GPU for the gather to the fusing device
         keep->device = device; keep->w = w; keep->h = h; keep->cam = cams[0];
         keep->depth = (float*)tsar_device_alloc(device, np * 4);
@@ -335,6 +381,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     if (!shared) tsar_destroy(ctx);
     hr.out_dir = out_dir; hr.w = w; hr.h = h;
     if (!defer_write && !write_view_files(hr)) return -1;      // deferred: the caller writes while the next view is being matched
+    if (!defer_write) stamp("write .dmb");
+    if (o.timing) printf("view %08d steps (ms): %s\n", ref_id, steps.c_str());
     if (o.display_outputs) {   // the reference always writes these two; here on request (a full-size view's PLY is 0.66 GB)
         std::vector<uint16_t> vis(3 * np);
         for (size_t k = 0; k < 3 * np; k++) {
@@ -477,7 +525,14 @@ int main(int argc, char** argv) {
     for (int s : slots)
         if (s < 1 || s >= (int)o.images.size()) { fprintf(stderr, "pair.txt refers to view slot %d but only %zu images were given\n", s, o.images.size()); return 1; }
     double sec = 0;
-    const int rc = run_view(o, 0, o.images, slots, camera_id, &sec);
+    // one view per process (the reference's shell loop): the context and the buffers stay alive until the process ends, and the
+    // process ends without tearing them down one by one — the files are on disk, the driver reclaims the rest (0.25 s of a 1.4 s
+    // invocation at ETH3D size went into freeing 1.5 GB of host buffers, the context and the runtime's own shutdown)
+    static HostResult single;
+    static tsar_ctx* single_ctx = nullptr;
+    single.shared_ctx = &single_ctx;
+    const int rc = run_view(o, 0, o.images, slots, camera_id, &sec, nullptr, &single);
     printf("Total runtime including disk i/o: %gsec\n", sec);
-    return rc == 0 ? 0 : 1;
+    fflush(nullptr);
+    _exit(rc == 0 ? 0 : 1);
 }
