@@ -500,6 +500,39 @@ def _prepared_pair(sc, seed, flags=0):
     return orc, m
 
 
+def test_reference_only_context_serves_the_refinement_operators(small_scene):
+    """tsar_set_views with the reference view alone: none of the textureless-refinement operators reads a source image, so
+    they give the same result as with all views loaded; the matching entry points refuse"""
+    sc = small_scene
+    rng = np.random.default_rng(2)
+    depth = rng.uniform(sc.depth_min, sc.depth_max, (sc.h, sc.w)).astype(np.float32)
+    normal = rng.normal(size=(sc.h, sc.w, 3)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=-1, keepdims=True)
+    good = (rng.uniform(size=(sc.h, sc.w)) < 0.7).astype(np.float32)
+    outs = []
+    for n in (1, len(sc.images)):
+        m = api.Matcher()
+        m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max))
+        m.set_views(sc.images[:n], sc.K[:n], sc.R[:n], sc.t[:n])
+        m.load_planes(depth, normal)
+        m.set_reliable_mask(good)
+        labels, text, size = m.detect_weak_texture()
+        m.getview()
+        planes, ratio = m.ransac_regions()
+        m.fake_depth()
+        m.fill_textureless()
+        res = m.get_result(("depth", "normal"))
+        outs.append((labels, text, size, planes, ratio, res["depth"], res["normal"]))
+        if n == 1:
+            for call in (m.pm_init, lambda: m.pm_iterate(1), m.lrdiff):
+                with pytest.raises(api.TsarError) as e:
+                    call()
+                assert e.value.code == api.TSAR_ERR_STATE
+        m.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 def test_wmf_detect_and_fill_bit_exact(small_scene):
     sc = small_scene
     h, w = sc.h, sc.w
