@@ -49,7 +49,7 @@ def _random_planes(scene, orc, seed):
 # even radii put the centre pixel among the taps; 25 and 31 are beyond what the per-thread weight table could hold.
 @pytest.mark.parametrize("box,n_best,comb", [(11, 1, 1), (11, 2, 1), (7, 3, 1), (11, 1, 0), (19, 2, 1), (11, 1, 2), (11, 1, 3),
                                              (1, 1, 1), (3, 1, 1), (5, 2, 1), (9, 1, 1), (13, 1, 1), (15, 2, 1), (17, 1, 0), (21, 1, 1),
-                                             (23, 4, 1), (25, 1, 1), (31, 2, 1), ((7, 13), 1, 1), ((19, 5), 2, 1), ((3, 27), 1, 1), (11, 3, 1), (11, 4, 1), (11, 5, 1), (9, 4, 0)])
+                                             (23, 4, 1), (25, 1, 1), (31, 2, 1), ((7, 13), 1, 1), ((19, 5), 2, 1), ((3, 27), 1, 1), (11, 3, 1), (11, 4, 1), (11, 5, 1), (9, 4, 0), (63, 1, 1), ((63, 9), 2, 1), ((5, 61), 1, 1), (45, 1, 1)])
 def test_cost_planes_strict_bit_exact(small_scene, box, n_best, comb):
     sc = small_scene
     box, box_v = box if isinstance(box, tuple) else (box, box)
@@ -64,7 +64,7 @@ def test_cost_planes_strict_bit_exact(small_scene, box, n_best, comb):
     m.close()
 
 
-@pytest.mark.parametrize("box,n_best", [(11, 1), (19, 2), (7, 1), (9, 3), (11, 3), (11, 4), (11, 6), ((15, 9), 1), (25, 1)])
+@pytest.mark.parametrize("box,n_best", [(11, 1), (19, 2), (7, 1), (9, 3), (11, 3), (11, 4), (11, 6), ((15, 9), 1), (25, 1), (63, 1)])
 def test_cost_planes_fast_tolerance(small_scene, box, n_best):
     sc = small_scene
     box, box_v = box if isinstance(box, tuple) else (box, box)

@@ -237,8 +237,10 @@ struct HostResult {
     int w = 0, h = 0;
     tsar_ctx** shared_ctx = nullptr;   // --all: the worker's context, kept across its views (device planes are allocated once)
 };
-static bool write_view_files(const HostResult& r) {
-    return write_dmb(r.out_dir + "TSAR_disp.dmb", r.depth.data(), r.h, r.w, 1) && write_dmb(r.out_dir + "TSAR_normals.dmb", r.normal.data(), r.h, r.w, 3);
+static bool write_view_files(const HostResult& r) {   // the two files side by side: a write is a copy into the page cache
+    auto normals = std::async(std::launch::async, [&r]() { return write_dmb(r.out_dir + "TSAR_normals.dmb", r.normal.data(), r.h, r.w, 3); });
+    const bool depth_ok = write_dmb(r.out_dir + "TSAR_disp.dmb", r.depth.data(), r.h, r.w, 1);
+    return normals.get() && depth_ok;
 }
 
 static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds,
