@@ -282,10 +282,9 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
             decoding.push_back(std::async(std::launch::async, [&o, &names, i]() { return g_images.get(o.images_folder + pnm_name(names[i], o.color ? ".ppm" : ".pgm")); }));
         for (int i = 0; i < n; i++) gray[i] = decoding[i].get();
     }
-    // (every helper thread started above is joined before any return below: they reference this frame)
+    // (the map / mask readers are joined where their data is needed — set_views and load_planes run while weak.png is still
+    // inflating — or by their futures' destructors on an early return: they reference this frame, which outlives them)
     const int create_rc = creating.valid() ? creating.get() : TSAR_OK;
-    if (reading_maps.valid()) reading_maps.get();
-    if (reading_mask.valid()) reading_mask.get();
     if (create_rc != TSAR_OK) { fprintf(stderr, "tsar_create(device %d) failed: %d\n", device, create_rc); return create_rc; }
     if (shared) *shared = ctx;
     // a context is destroyed here only when this call owns it, or after a failure (the next view then starts from a fresh one)
@@ -324,7 +323,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0) |
               (o.tex8 ? TSAR_FLAG_TEX_FILTER_8BIT : 0);
     if (tsar_set_params(ctx, &p) != TSAR_OK) return fail("tsar_set_params");
-    stamp(external ? "context + reference image + external maps + weak.png (concurrent)" : "context + images + cameras (concurrent)");
+    if (o.timing) { tsar_enable_kernel_timing(ctx, 1); tsar_reset_kernel_timing(ctx); }
+    stamp(external ? "context + reference image (external maps and weak.png still loading)" : "context + images + cameras (concurrent)");
     const bool resident = (int)dev_ptrs.size() == n;
     if (tsar_set_views(ctx, n, w, h, resident ? dev_ptrs.data() : ptrs.data(), resident ? TSAR_MEM_DEVICE : TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
     if (!subset_slots.empty() && !external) {
@@ -341,6 +341,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     if (hr.depth.size() != np) sizing = std::async(std::launch::async, [&hr, np]() { hr.depth.resize(np); hr.normal.resize(3 * np); });
     struct JoinSizing { std::future<void>& f; ~JoinSizing() { if (f.valid()) f.get(); } } join_sizing{sizing};   // on every return path
     if (external) {
+        reading_maps.get();
         if (!ext.depth_ok || ext.dh != h || ext.dw != w || ext.dnb != 1) { fprintf(stderr, "cannot read %sdepths_geom.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
         if (!ext.normal_ok || ext.nh != h || ext.nw != w || ext.nnb != 3) { fprintf(stderr, "cannot read %snormals.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
         if (tsar_load_planes(ctx, ext.depth.data(), ext.normal.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_load_planes");
@@ -354,6 +355,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         // the reference's live path, runGipuma main.cpp:1493-1783: external planes (above: firstcuda) -> reliability mask
         // from weak.png -> weak-texture regions of the reference image (texture(), main.cpp:214-596) -> sliccuda
         // (gipuma_getview) -> per-region plane RANSAC (:1520-1730) -> fakecuda -> fillcuda
+        reading_mask.get();
+        stamp("weak.png (rest of its inflate)");
         if (!ext.mask_ok || ext.mw != w || ext.mh != h) { fprintf(stderr, "cannot read %sweak.png (8-bit PNG of the image size)\n", out_dir.c_str()); drop_ctx(); return -1; }
         if (tsar_set_reliable_mask(ctx, ext.scale.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_set_reliable_mask");
         stamp("set_reliable_mask");
@@ -380,11 +383,20 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         if (!keep->depth || !keep->normal) return fail("tsar_device_alloc");
         if (tsar_get_result(ctx, keep->depth, keep->normal, nullptr, nullptr, TSAR_MEM_DEVICE) != TSAR_OK) return fail("tsar_get_result (device)");
     }
-    if (!shared) tsar_destroy(ctx);
     hr.out_dir = out_dir; hr.w = w; hr.h = h;
     if (!defer_write && !write_view_files(hr)) return -1;      // deferred: the caller writes while the next view is being matched
     if (!defer_write) stamp("write .dmb");
-    if (o.timing) printf("view %08d steps (ms): %s\n", ref_id, steps.c_str());
+    if (o.timing) {
+        printf("view %08d steps (ms): %s\n", ref_id, steps.c_str());
+        tsar_kernel_timing kt[64];
+        int nk = 0;
+        if (tsar_get_kernel_timing(ctx, kt, 64, &nk) == TSAR_OK) {
+            printf("view %08d kernels (launches x mean ms):", ref_id);
+            for (int k = 0; k < nk && k < 64; k++) printf(" %s %d x %.3f |", kt[k].name, kt[k].launches, kt[k].launches ? kt[k].total_ms / kt[k].launches : 0.0);
+            printf("\n");
+        }
+    }
+    if (!shared) tsar_destroy(ctx);
     if (o.display_outputs) {   // the reference always writes these two; here on request (a full-size view's PLY is 0.66 GB)
         std::vector<uint16_t> vis(3 * np);
         for (size_t k = 0; k < 3 * np; k++) {
