@@ -205,7 +205,9 @@ def main():
     backend = os.environ.get("TSAR_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # TSAR_BENCH_FORCE_DIST=1: also take the collective path with ONE rank (torch.distributed.run --nproc-per-node 1): the RCCL
+    # communicator, the asynchronous gather, the barrier and the all-reduce then run on real hardware even on a one-GPU box
+    if world > 1 or (os.environ.get("TSAR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

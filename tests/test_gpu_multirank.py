@@ -27,9 +27,9 @@ def _free_port():
     return p
 
 
-def _run_bench(world, extra, env_extra=None, timeout=600):
+def _run_bench(world, extra, env_extra=None, timeout=600, backend="gloo"):
     env = dict(os.environ)
-    env.update({"TSAR_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
+    env.update({"TSAR_BENCH_BACKEND": backend, "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
     env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
@@ -58,3 +58,15 @@ def test_bench_three_ranks_odd_step_count():
                           "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing"])
     assert line["gather_check"]["verified"] is True and line["gather_check"]["ranks_differ"] is True
     assert len(line["gather_check"]["per_rank_depth_checksum"]) == 3
+
+
+def test_bench_one_rank_through_rccl():
+    """the collective path on the RCCL backend itself, with the one rank a one-GPU box allows (TSAR_BENCH_FORCE_DIST=1):
+    communicator creation, the asynchronous double-buffered gather on the collective's stream beside the next view's kernels,
+    barrier and all-reduce — everything of the N > 1 path but bytes crossing xGMI"""
+    line = _run_bench(1, ["--steps", "3", "--warmup", "1", "--width", "1280", "--height", "960", "--views", "4", "--iters", "2",
+                          "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing", "--no-host-boundary", "--no-strict-record"],
+                      env_extra={"TSAR_BENCH_FORCE_DIST": "1"}, backend="nccl")
+    assert line["gather_check"]["verified"] is True, line["gather_check"]
+    assert line["n_gpus"] == 1 and line["steps"] == 3
+    assert line["config"]["frac_depth_within_1pct_of_gt"] > 0.5
