@@ -220,6 +220,45 @@ def test_cli_tsar_mode_is_the_reference_live_path(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_all_views_tsar_mode_equals_one_process_per_view(tmp_path):
+    """--all --mode=tsar (one process, inputs of the next views read ahead into a ring of page-locked buffers while a view is on
+    the GPU, reference-only contexts) writes the same bytes as one invocation per view"""
+    sc = synth.make_scene(608, 416, 4, seed=6, textureless=True, flat_cell=3.0, all_gt=True)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    rng = np.random.default_rng(4)
+    n = len(sc.images)
+    good = sc.textured.numpy() | (rng.uniform(size=(sc.h, sc.w)) < 0.1)
+    for v in range(n):
+        gt, nc = sc.meta["gt_all"][v]
+        gt = gt.numpy()
+        depth = (gt * (1 + rng.normal(0, 0.002, gt.shape))).astype(np.float32)
+        junk = rng.uniform(sc.depth_min, sc.depth_max, gt.shape).astype(np.float32)
+        depth[~good] = junk[~good]
+        apd = root + f"APD/{v:08d}/"
+        os.makedirs(apd, exist_ok=True)
+        tio.write_dmb(apd + "depths_geom.dmb", depth)
+        tio.write_dmb(apd + "normals.dmb", np.ascontiguousarray((nc.numpy() @ sc.R[v]).astype(np.float32)))
+        tio.write_reliable_mask(apd + "weak.png", good)
+    common = ["-mslp_folder", root, "-images_folder", root + "images/", "--blocksize=11", "--n_best=1", "--mode=tsar"]
+    out = subprocess.run([CLI, "--all", "--gpus=1", *common], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    together = {v: (open(root + f"APD/{v:08d}/TSAR_disp.dmb", "rb").read(), open(root + f"APD/{v:08d}/TSAR_normals.dmb", "rb").read()) for v in range(n)}
+    for v in range(n):
+        os.remove(root + f"APD/{v:08d}/TSAR_disp.dmb")
+        os.remove(root + f"APD/{v:08d}/TSAR_normals.dmb")
+        names = [f"{v:08d}.pgm"] + [f"{s:08d}.pgm" for s in range(n) if s != v]     # the reference's argv: reference first
+        one = subprocess.run([CLI, *names, *common], capture_output=True, text=True)
+        assert one.returncode == 0, one.stdout + one.stderr
+        assert open(root + f"APD/{v:08d}/TSAR_disp.dmb", "rb").read() == together[v][0]
+        assert open(root + f"APD/{v:08d}/TSAR_normals.dmb", "rb").read() == together[v][1]
+    # the refinement did run: the output differs from the external depth inside the unreliable pixels
+    d0 = tio.read_dmb(root + "APD/00000000/TSAR_disp.dmb")
+    ext0 = tio.read_dmb(root + "APD/00000000/depths_geom.dmb")
+    assert (d0 != ext0).mean() > 0.01
+
+
+@pytest.mark.gpu
 def test_cli_color_processing_matches_on_the_blue_channel(tmp_path):
     """-color_processing: the reference uploads BGRA float4 textures but its cost fetches tex2D<float>, i.e. the first
     (blue) channel (gipuma.cu:247,262,265; main.cpp:1427-1447).  PPM in, same outputs as the gray run on that channel."""

@@ -228,6 +228,38 @@ struct DeviceResult {
     tsar_camera cam{};
 };
 
+// What the refinement modes read per view besides the reference image: the external depth / normal maps and (--mode=tsar)
+// weak.png.  Loaded by helper threads; in --all runs a worker keeps two of these, page-locked, and starts loading view k+1's
+// while view k is on the GPU (inflating a full-size weak.png alone takes longer than the view's kernels).
+struct ExternalInputs {
+    bool pinned = false;                       // --all: buffers reused by every view of the worker, worth page-locking
+    PinnedFloats pdepth, pnormal;
+    std::vector<float> vdepth, vnormal, scale;
+    int dh = 0, dw = 0, dnb = 0, nh = 0, nw = 0, nnb = 0, mw = 0, mh = 0;
+    bool depth_ok = false, normal_ok = false, mask_ok = false, started = false;
+    std::string dir;
+    std::future<void> maps, mask;
+    const float* depth() const { return pinned ? pdepth.data() : vdepth.data(); }
+    const float* normal() const { return pinned ? pnormal.data() : vnormal.data(); }
+    void start(const std::string& view_dir, bool want_mask, const std::string& ref_image_path);
+};
+void ExternalInputs::start(const std::string& view_dir, bool want_mask, const std::string& ref_image_path) {
+    dir = view_dir;
+    started = true;
+    depth_ok = normal_ok = mask_ok = false;
+    maps = std::async(std::launch::async, [this, ref_image_path]() {
+        if (pinned) {
+            depth_ok = read_dmb(dir + "depths_geom.dmb", pdepth, dh, dw, dnb);
+            normal_ok = read_dmb(dir + "normals.dmb", pnormal, nh, nw, nnb);
+        } else {
+            depth_ok = read_dmb(dir + "depths_geom.dmb", vdepth, dh, dw, dnb);
+            normal_ok = read_dmb(dir + "normals.dmb", vnormal, nh, nw, nnb);
+        }
+        if (!ref_image_path.empty()) g_images.get(ref_image_path);      // a prefetch: decoded into the cache for the view's own start
+    });
+    if (want_mask) mask = std::async(std::launch::async, [this]() { mask_ok = read_reliable_mask(dir + "weak.png", scale, mw, mh); });
+}
+
 // one reference view: images[0] is the reference, the rest the candidate sources in argv order
 // page-locked result buffers of one worker, allocated once and reused for every view it processes (page-locking 390 MB per view
 // would cost more than the copy it speeds up)
@@ -244,7 +276,7 @@ static bool write_view_files(const HostResult& r) {   // the two files side by s
 }
 
 static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds,
-                    DeviceResult* keep = nullptr, HostResult* reuse = nullptr, bool defer_write = false) {
+                    DeviceResult* keep = nullptr, HostResult* reuse = nullptr, bool defer_write = false, ExternalInputs* preloaded = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
     auto t_last = t0;
     std::string steps;                                            // --timing: "step ms | step ms | ..."
@@ -268,13 +300,10 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     tsar_ctx* ctx = shared ? *shared : nullptr;
     std::future<int> creating;
     if (!ctx) creating = std::async(std::launch::async, [&ctx, device]() { return tsar_create(device, &ctx); });
-    struct ExternalMaps { std::vector<float> depth, normal, scale; int dh = 0, dw = 0, dnb = 0, nh = 0, nw = 0, nnb = 0, mw = 0, mh = 0; bool depth_ok = false, normal_ok = false, mask_ok = false; } ext;
-    std::future<void> reading_maps, reading_mask;
-    if (external) reading_maps = std::async(std::launch::async, [&]() {
-        ext.depth_ok = read_dmb(out_dir + "depths_geom.dmb", ext.depth, ext.dh, ext.dw, ext.dnb);
-        ext.normal_ok = read_dmb(out_dir + "normals.dmb", ext.normal, ext.nh, ext.nw, ext.nnb);
-    });
-    if (tsar_mode) reading_mask = std::async(std::launch::async, [&]() { ext.mask_ok = read_reliable_mask(out_dir + "weak.png", ext.scale, ext.mw, ext.mh); });
+    ExternalInputs own_inputs;
+    ExternalInputs& ext = (preloaded && preloaded->started && preloaded->dir == out_dir) ? *preloaded : own_inputs;   // --all: started a view ago
+    if (external && !ext.started) ext.start(out_dir, tsar_mode, "");
+    struct Consumed { ExternalInputs& e; ~Consumed() { if (e.maps.valid()) e.maps.get(); if (e.mask.valid()) e.mask.get(); e.started = false; } } consumed{ext};
     std::vector<std::shared_ptr<ImageCache::Entry>> gray(n);
     {
         std::vector<std::future<std::shared_ptr<ImageCache::Entry>>> decoding;
@@ -283,7 +312,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         for (int i = 0; i < n; i++) gray[i] = decoding[i].get();
     }
     // (the map / mask readers are joined where their data is needed — set_views and load_planes run while weak.png is still
-    // inflating — or by their futures' destructors on an early return: they reference this frame, which outlives them)
+    // inflating — or by `consumed` on an early return)
     const int create_rc = creating.valid() ? creating.get() : TSAR_OK;
     if (create_rc != TSAR_OK) { fprintf(stderr, "tsar_create(device %d) failed: %d\n", device, create_rc); return create_rc; }
     if (shared) *shared = ctx;
@@ -341,10 +370,10 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     if (hr.depth.size() != np) sizing = std::async(std::launch::async, [&hr, np]() { hr.depth.resize(np); hr.normal.resize(3 * np); });
     struct JoinSizing { std::future<void>& f; ~JoinSizing() { if (f.valid()) f.get(); } } join_sizing{sizing};   // on every return path
     if (external) {
-        reading_maps.get();
+        if (ext.maps.valid()) ext.maps.get();
         if (!ext.depth_ok || ext.dh != h || ext.dw != w || ext.dnb != 1) { fprintf(stderr, "cannot read %sdepths_geom.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
         if (!ext.normal_ok || ext.nh != h || ext.nw != w || ext.nnb != 3) { fprintf(stderr, "cannot read %snormals.dmb\n", out_dir.c_str()); drop_ctx(); return -1; }
-        if (tsar_load_planes(ctx, ext.depth.data(), ext.normal.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_load_planes");
+        if (tsar_load_planes(ctx, ext.depth(), ext.normal(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_load_planes");
         stamp("load_planes");
     } else {
         if (tsar_pm_init(ctx) != TSAR_OK) return fail("tsar_pm_init");
@@ -355,7 +384,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         // the reference's live path, runGipuma main.cpp:1493-1783: external planes (above: firstcuda) -> reliability mask
         // from weak.png -> weak-texture regions of the reference image (texture(), main.cpp:214-596) -> sliccuda
         // (gipuma_getview) -> per-region plane RANSAC (:1520-1730) -> fakecuda -> fillcuda
-        reading_mask.get();
+        if (ext.mask.valid()) ext.mask.get();
         stamp("weak.png (rest of its inflate)");
         if (!ext.mask_ok || ext.mw != w || ext.mh != h) { fprintf(stderr, "cannot read %sweak.png (8-bit PNG of the image size)\n", out_dir.c_str()); drop_ctx(); return -1; }
         if (tsar_set_reliable_mask(ctx, ext.scale.data(), TSAR_MEM_HOST) != TSAR_OK) return fail("tsar_set_reliable_mask");
@@ -441,6 +470,14 @@ int main(int argc, char** argv) {
                 tsar_ctx* worker_ctx = nullptr;
                 host_result[0].shared_ctx = host_result[1].shared_ctx = &worker_ctx;
                 std::future<bool> writing[2];
+                // refinement modes: a ring of (page-locked) input buffers; the maps, weak.png and reference image of the next three
+                // views are read while view k is on the GPU (one weak.png inflates in ~0.3 s, a view's kernels take ~0.1 s)
+                const bool external = o.mode == "load" || o.mode == "tsar";
+                constexpr size_t RING = 4;
+                ExternalInputs inputs[RING];
+                for (auto& in : inputs) in.pinned = true;
+                auto view_dir = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d", ref); return o.mslp_folder + "APD/" + b + "/"; };
+                auto ref_image = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d.pgm", ref); return o.images_folder + pnm_name(b, o.color ? ".ppm" : ".pgm"); };
                 size_t turn = 0;
                 for (size_t k = t; k < refs.size(); k += nthr, turn++) {   // round-robin: every view of a scene costs the same
                     const int ref = refs[k];
@@ -452,7 +489,15 @@ int main(int argc, char** argv) {
                     double sec = 0;
                     HostResult& hr = host_result[turn & 1];
                     if (writing[turn & 1].valid() && !writing[turn & 1].get()) status[t] = -1;      // the set's previous files are on disk
-                    const int rc = run_view(o, g, names, {}, ref, &sec, o.fuse ? &kept[k] : nullptr, &hr, /*defer_write*/ true);
+                    if (external) {
+                        if (!inputs[turn % RING].started) inputs[turn % RING].start(view_dir(ref), o.mode == "tsar", "");
+                        for (size_t j = 1; j < RING; j++) {
+                            ExternalInputs& ahead = inputs[(turn + j) % RING];
+                            const size_t kk = k + j * nthr;
+                            if (kk < refs.size() && !ahead.started) ahead.start(view_dir(refs[kk]), o.mode == "tsar", ref_image(refs[kk]));
+                        }
+                    }
+                    const int rc = run_view(o, g, names, {}, ref, &sec, o.fuse ? &kept[k] : nullptr, &hr, /*defer_write*/ true, external ? &inputs[turn % RING] : nullptr);
                     printf("view %08d on gpu %d: %s (%.2f s)\n", ref, g, rc == 0 ? "ok" : "FAILED", sec);
                     if (rc != 0) status[t] = rc;   // a failed view does not stop the others
                     else writing[turn & 1] = std::async(std::launch::async, [&hr]() { return write_view_files(hr); });

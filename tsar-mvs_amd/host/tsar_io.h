@@ -119,7 +119,8 @@ static inline bool write_dmb(const std::string& path, const float* data, int h, 
     fclose(f);
     return ok;
 }
-static inline bool read_dmb(const std::string& path, std::vector<float>& data, int& h, int& w, int& nb) {
+template <class FloatVector>   // std::vector<float> with any allocator
+static inline bool read_dmb(const std::string& path, FloatVector& data, int& h, int& w, int& nb) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     int32_t hdr[4];
