@@ -517,6 +517,8 @@ def test_reference_only_context_serves_the_refinement_operators(small_scene):
         m.load_planes(depth, normal)
         m.set_reliable_mask(good)
         labels, text, size = m.detect_weak_texture()
+        labels2, text2, size2 = m.detect_weak_texture()          # second call: temporaries recycled from the scratch arena
+        assert np.array_equal(labels, labels2) and np.array_equal(text, text2) and np.array_equal(size, size2)
         m.getview()
         planes, ratio = m.ransac_regions()
         m.fake_depth()
@@ -588,6 +590,9 @@ def test_ransac_regions_bit_exact(mid_scene, monkeypatch, lookahead):
     planes, ratio = m.ransac_regions()
     assert np.array_equal(planes[1:].view(np.uint32), planes_ref[1:].view(np.uint32))
     assert np.array_equal(ratio, ratio_ref)
+    # again in the same context: the second call takes its temporaries from the context's scratch arena (recycled, not zeroed)
+    planes2, ratio2 = m.ransac_regions()
+    assert np.array_equal(planes2.view(np.uint32), planes.view(np.uint32)) and np.array_equal(ratio2, ratio)
     # the slanted plane is recovered: normal parallel to the analytic one
     n_gt = sc.gt_normal.numpy()[labels == 1].mean(0)
     n_gt /= np.linalg.norm(n_gt)

@@ -68,6 +68,9 @@ def main():
             ok = out.returncode == 0
             print(f"run {r}: {dt:.2f} s for {n_done} {args.width}x{args.height} view(s) = {n_done * args.width * args.height / dt / 1e6:.1f} Mpix/s files-to-files, {'ok' if ok else 'FAILED'}", flush=True)
             print("   " + " | ".join(l for l in out.stdout.strip().splitlines()[-12:]), flush=True)
+            trace = [ln for ln in out.stderr.splitlines() if ln.startswith("[")]       # TSAR_TRACE_HOST=1: host-side steps of the operators
+            if trace:
+                print("   " + " | ".join(trace[-40:]), flush=True)
             if not ok:
                 print(out.stderr[-2000:])
                 sys.exit(1)

@@ -12,6 +12,8 @@
 //
 // Deterministic choices (the reference uses rand() and a time-seeded shuffle): raster-order point
 // lists, even subsampling to 49999 points above 50000, Philox draws keyed by (draw, stage, region).
+#include <chrono>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -37,7 +39,19 @@ __global__ void ransac_keys_kernel(const uint32_t* __restrict__ pix, int n, cons
     if (i >= n) return;
     const uint32_t s = (uint32_t)slot_of_region[canny[pix[i]]];
     keys[i] = s;
-    atomicAdd(&counts[s], 1);
+    // one atomic per distinct slot of the wave: the list is in raster order, so a wave's 64 pixels lie in one or two regions,
+    // and a few large regions would otherwise serialise millions of atomics on a handful of addresses (13 ms at 24 MP).
+    // (The loop is wave-uniform over a mask that shrinks every trip; a `while (pending)` loop around readfirstlane(s) is folded
+    // by the compiler into a single trip — the read is loop-invariant to it, and a trip that does not exit would never end.)
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(1);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t lead = (uint32_t)__shfl((int)s, first);
+        const unsigned long long same = __ballot(s == lead);
+        if (lane == first) atomicAdd(&counts[lead], __popcll(same));
+        todo &= ~same;
+    }
 }
 
 // main.cpp:1571-1594: depth from lines->depth (= f*b/depth), back-projection through M^-1
@@ -372,15 +386,19 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
     const int nreg = ctx->n_regions;
     const size_t np = (size_t)ctx->w * ctx->h;
     hipStream_t st = ctx->stream;
+    static const bool trace = getenv("TSAR_TRACE_HOST") != nullptr;
+    auto tr0 = std::chrono::steady_clock::now();
+    auto TR = [&](const char* what) { if (trace) { hipStreamSynchronize(st); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[ransac] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tr0).count()); tr0 = n; } };
     std::vector<float> text(nreg);
     std::vector<int32_t> slot_of_region(nreg, -1), region_of_slot;
     if (hipMemcpy(text.data(), ctx->region_text, (size_t)nreg * 4, hipMemcpyDeviceToHost) != hipSuccess) { ctx->err = "D2H failed"; return TSAR_ERR_HIP; }
     for (int r = 0; r < nreg; r++)
         if (text[r] == -1.0f) { slot_of_region[r] = (int)region_of_slot.size(); region_of_slot.push_back(r); }
     const int nslot = (int)region_of_slot.size();
-    std::vector<void*> to_free;
-    auto dmalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; to_free.push_back(p); return p; };
-    auto done = [&](int rc, const char* msg) { if (msg) ctx->err = msg; hipStreamSynchronize(st); for (void* p : to_free) hipFree(p); return rc; };
+    TR("text D2H + slots");
+    ScratchScope scratch(ctx);           // temporaries come out of the context's arena (tsar_dev.h)
+    auto dmalloc = [&](size_t bytes) -> void* { return scratch.alloc(bytes); };
+    auto done = [&](int rc, const char* msg) { if (msg) ctx->err = msg; hipStreamSynchronize(st); scratch.release(); return rc; };
     float* d_ratio = (float*)dmalloc((size_t)nreg * 4);
     if (!d_ratio) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
     hipMemsetAsync(d_ratio, 0, (size_t)nreg * 4, st);
@@ -394,6 +412,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         hipMemcpyAsync(d_slot_of_region, slot_of_region.data(), (size_t)nreg * 4, hipMemcpyHostToDevice, st);
         hipMemcpyAsync(d_region_of_slot, region_of_slot.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
         hipMemsetAsync(d_counts, 0, (size_t)nslot * 4, st);
+        TR("allocs + uploads");
         // (1) raster-order list of reliable pixels inside textureless regions (main.cpp:1527-1536)
         uint8_t* d_flag = (uint8_t*)dmalloc(np);
         if (!d_flag) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
@@ -410,6 +429,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         uint32_t nsel = 0;
         hipMemcpyAsync(&nsel, d_nsel, 4, hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "select failed");
+        TR("select");
         std::vector<int> counts(nslot, 0), slot_start(nslot, 0), pts_start(nslot, 0), pts_count(nslot, 0);
         float* d_pts = nullptr;
         int *d_slot_start = (int*)dmalloc((size_t)nslot * 4), *d_pts_start = (int*)dmalloc((size_t)nslot * 4), *d_pts_count = (int*)dmalloc((size_t)nslot * 4);
@@ -431,6 +451,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
             }
             hipMemcpyAsync(counts.data(), d_counts, (size_t)nslot * 4, hipMemcpyDeviceToHost, st);
             if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "sort failed");
+            TR("keys + sort + counts D2H");
             int acc = 0, pacc = 0;
             for (int s = 0; s < nslot; s++) {
                 slot_start[s] = acc; acc += counts[s];
@@ -452,6 +473,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
             hipMemcpyAsync(d_pts_start, pts_start.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
         }
         hipMemcpyAsync(d_pts_count, pts_count.data(), (size_t)nslot * 4, hipMemcpyHostToDevice, st);
+        TR("points");
         RansacState* d_state = (RansacState*)dmalloc((size_t)nslot * sizeof(RansacState));
         int* d_cnt = (int*)dmalloc((size_t)nslot * RS_PHASE * sizeof(int));
         if (!d_state || !d_cnt) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
@@ -472,9 +494,11 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                                ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio);
         }
         if (hipGetLastError() != hipSuccess) return done(TSAR_ERR_HIP, "ransac launch failed");
+        TR("fit");
     }
     if (region_planes_out) hipMemcpyAsync(region_planes_out, ctx->region_n4, (size_t)nreg * 16, hipMemcpyDeviceToHost, st);
     if (inlier_ratio_out) hipMemcpyAsync(inlier_ratio_out, d_ratio, (size_t)nreg * 4, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "ransac kernel failed");
+    TR("outputs D2H");
     return done(TSAR_OK, nullptr);
 }

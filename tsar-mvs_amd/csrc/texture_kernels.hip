@@ -12,6 +12,7 @@
 // Deviations: the HoughLinesP boundary closing (main.cpp:391-435) is OpenCV-internal and
 // randomised and is not reproduced; components are the true 4-connected ones, whereas Connect()'s parent
 // overwrite can lose a link in rare shapes.
+#include <chrono>
 #include <rocprim/device/device_scan.hpp>
 
 #include "tsar_dev.h"
@@ -124,9 +125,23 @@ __global__ void tx_ccl_flatten_kernel(const uint8_t* __restrict__ img, int* pare
 #define TX_WEAK_COUNT 5000
 #define TX_MAX_WEAK 1024
 
+// counts[key] += 1 for every lane with valid set, one atomic per distinct key of the wave: neighbouring pixels mostly share their
+// component, and a few large components would otherwise serialise ~10^6 atomics on a handful of addresses (milliseconds)
+static __device__ __forceinline__ void wave_count_add(int* __restrict__ counts, int key, bool valid) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);                  // wave-uniform loop over a mask that shrinks every trip
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const int lead = __shfl(key, first);
+        const unsigned long long same = __ballot(valid && key == lead);
+        if (lane == first) atomicAdd(&counts[lead], __popcll(same));
+        todo &= ~same;
+    }
+}
 __global__ void tx_root_count_kernel(const int* __restrict__ root, int* __restrict__ cnt, int n) {
     const int p = blockIdx.x * TX_BLOCK + threadIdx.x;
-    if (p < n && root[p] >= 0) atomicAdd(&cnt[root[p]], 1);
+    const int r = p < n ? root[p] : -1;
+    wave_count_add(cnt, r, r >= 0);
 }
 __global__ void tx_weak_roots_kernel(const int* __restrict__ cnt, int n, int* __restrict__ list, int* __restrict__ nlist) {
     const int p = blockIdx.x * TX_BLOCK + threadIdx.x;
@@ -199,16 +214,41 @@ __global__ void tx_label_stats_kernel(const int* __restrict__ root, const int* _
                                       int* __restrict__ count, int* __restrict__ sumx, int* __restrict__ sumy, int* __restrict__ xmin,
                                       int* __restrict__ xmax, int* __restrict__ ymin, int* __restrict__ ymax) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (x >= w || y >= h) return;
-    const int p = y * w + x;
-    const int r = root[p];
-    const int l = r < 0 ? 0 : root_rank[r] + 1;
-    lab[p] = l;
-    atomicAdd(&count[l], 1);
-    atomicAdd(&sumx[l], x);
-    atomicAdd(&sumy[l], y);
-    atomicMin(&xmin[l], x); atomicMax(&xmax[l], x);
-    atomicMin(&ymin[l], y); atomicMax(&ymax[l], y);
+    const bool valid = x < w && y < h;
+    int l = 0;
+    if (valid) {
+        const int p = y * w + x;
+        const int r = root[p];
+        l = r < 0 ? 0 : root_rank[r] + 1;
+        lab[p] = l;
+    }
+    // one set of atomics per distinct label of the wave (its 64 pixels are two 32-pixel rows: one or two labels, mostly),
+    // the seven statistics reduced across the label's lanes first; integer sums and extrema: the result does not depend on order
+    const int lane = threadIdx.x & 63;
+    bool pending = valid;
+    unsigned long long todo = __ballot(pending);
+    while (todo) {                                              // wave-uniform
+        const int first = __ffsll((long long)todo) - 1;
+        const int lead = __shfl(l, first);
+        const bool mine = pending && l == lead;
+        int c = mine ? 1 : 0, sx = mine ? x : 0, sy = mine ? y : 0;
+        int x0 = mine ? x : INT32_MAX, x1 = mine ? x : INT32_MIN, y0 = mine ? y : INT32_MAX, y1 = mine ? y : INT32_MIN;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c += __shfl_xor(c, o); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o);
+            x0 = min(x0, __shfl_xor(x0, o)); x1 = max(x1, __shfl_xor(x1, o));
+            y0 = min(y0, __shfl_xor(y0, o)); y1 = max(y1, __shfl_xor(y1, o));
+        }
+        if (lane == first) {
+            atomicAdd(&count[lead], c);
+            atomicAdd(&sumx[lead], sx);
+            atomicAdd(&sumy[lead], sy);
+            atomicMin(&xmin[lead], x0); atomicMax(&xmax[lead], x1);
+            atomicMin(&ymin[lead], y0); atomicMax(&ymax[lead], y1);
+        }
+        pending = pending && !mine;
+        todo = __ballot(pending);
+    }
 }
 __global__ void tx_stats_init_kernel(int* xmin, int* xmax, int* ymin, int* ymax, int n, int w4, int h4) {
     const int i = blockIdx.x * TX_BLOCK + threadIdx.x;
@@ -252,9 +292,12 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
     if (w4 < 3 || h4 < 3) { ctx->err = "image too small for weak-texture detection"; return TSAR_ERR_INVALID; }
     const int n4 = w4 * h4;
     hipStream_t st = ctx->stream;
-    std::vector<void*> to_free;
-    auto dmalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; to_free.push_back(p); return p; };
-    auto done = [&](int rc, const char* msg) { if (msg) ctx->err = msg; hipStreamSynchronize(st); for (void* p : to_free) hipFree(p); return rc; };
+    static const bool trace = getenv("TSAR_TRACE_HOST") != nullptr;     // host-side steps on stderr (diagnostics)
+    auto tr0 = std::chrono::steady_clock::now();
+    auto TR = [&](const char* what) { if (trace) { hipStreamSynchronize(st); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[weak_texture] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tr0).count()); tr0 = n; } };
+    ScratchScope scratch(ctx);           // temporaries come out of the context's arena (tsar_dev.h)
+    auto dmalloc = [&](size_t bytes) -> void* { return scratch.alloc(bytes); };
+    auto done = [&](int rc, const char* msg) { if (msg) ctx->err = msg; hipStreamSynchronize(st); scratch.release(); return rc; };
     uint8_t *g0 = (uint8_t*)dmalloc((size_t)w * h), *g2 = (uint8_t*)dmalloc((size_t)w2 * h2), *g4 = (uint8_t*)dmalloc(n4), *edge = (uint8_t*)dmalloc(n4);
     int *parent = (int*)dmalloc((size_t)n4 * 4), *is_root = (int*)dmalloc((size_t)n4 * 4), *rank = (int*)dmalloc((size_t)n4 * 4);
     int32_t* lab4 = (int32_t*)dmalloc((size_t)n4 * 4);
@@ -268,6 +311,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
         hipLaunchKernelGGL(tx_pyrdown_kernel, grid2(w4, h4), b, 0, st, g2, w2, h2, g4);
         hipLaunchKernelGGL(tx_roberts_kernel, grid2(w4, h4), b, 0, st, g4, w4, h4, edge);
     }
+    TR("allocs + pyramid + edges");
     if (!(ctx->hscene.flags & TSAR_FLAG_NO_LINE_CLOSING)) {
         // first labelling (before the border fix) -> large components -> close gaps in their straight boundaries
         int* cnt0 = (int*)dmalloc((size_t)n4 * 4);
@@ -295,6 +339,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
         std::vector<int> hl(TX_MAX_WEAK + 1);
         hipMemcpyAsync(hl.data(), wlist, (size_t)TX_MAX_WEAK * 4 + 4, hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "weak-texture kernels failed");
+        TR("first labelling + large components D2H");
         const int nweak = hl[0] < TX_MAX_WEAK ? hl[0] : TX_MAX_WEAK;
         for (int k = 0; k < nweak; k++) {                     // independent of each other: masks come from the first labelling
             hipMemsetAsync(acc, 0, (size_t)180 * nrho * 4, st);
@@ -303,6 +348,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
             hipLaunchKernelGGL(tx_hough_segments_kernel, dim3((nrho + TX_BLOCK - 1) / TX_BLOCK, 180), b, 0, st, acc, nrho, rmax, tabs, tabs + 180, bmask, edge, w4, h4);
         }
     }
+    TR("line closing");
     {
         ScopedKernelTimer tm(ctx, "weak_texture_label");
         hipLaunchKernelGGL(tx_border_rows_kernel, dim3((h4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, w4, h4);
@@ -311,6 +357,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
         hipLaunchKernelGGL(tx_ccl_merge_kernel, grid2(w4, h4), b, 0, st, edge, parent, w4, h4);
         hipLaunchKernelGGL(tx_ccl_flatten_kernel, dim3((n4 + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, edge, parent, is_root, n4);
     }
+    TR("second labelling");
     size_t tmp_bytes = 0;
     if (rocprim::exclusive_scan(nullptr, tmp_bytes, is_root, rank, 0, (size_t)n4, rocprim::plus<int>(), st) != hipSuccess) return done(TSAR_ERR_HIP, "scan sizing failed");
     void* tmp = dmalloc(tmp_bytes);
@@ -320,6 +367,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
     hipMemcpyAsync(&last_rank, rank + (n4 - 1), 4, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(&last_flag, is_root + (n4 - 1), 4, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "weak-texture kernels failed");
+    TR("scan + count D2H");
     const int labelnum = last_rank + last_flag + 1;                          // + label 0 (edge pixels)
     int* stats = (int*)dmalloc((size_t)labelnum * 7 * 4);
     if (!stats) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
@@ -328,6 +376,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
     hipMemsetAsync(stats, 0, (size_t)labelnum * 3 * 4, st);
     hipLaunchKernelGGL(tx_stats_init_kernel, dim3((labelnum + TX_BLOCK - 1) / TX_BLOCK), b, 0, st, xmin, xmax, ymin, ymax, labelnum, w4, h4);
     hipLaunchKernelGGL(tx_label_stats_kernel, grid2(w4, h4), b, 0, st, parent, rank, lab4, w4, h4, count, sumx, sumy, xmin, xmax, ymin, ymax);
+    TR("label statistics");
     // install as the context's regions
     hipFree(ctx->region_text); hipFree(ctx->region_size); hipFree(ctx->region_n4);
     ctx->region_text = nullptr; ctx->region_size = nullptr; ctx->region_n4 = nullptr;
@@ -343,5 +392,6 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
     if (text_out) hipMemcpyAsync(text_out, ctx->region_text, (size_t)(labelnum < cap ? labelnum : cap) * 4, hipMemcpyDeviceToHost, st);
     if (size_out) hipMemcpyAsync(size_out, ctx->region_size, (size_t)(labelnum < cap ? labelnum : cap) * 4, hipMemcpyDeviceToHost, st);
     if (n_regions_out) *n_regions_out = labelnum;
+    TR("region tables + classify + upsample + outputs");
     return done(hipStreamSynchronize(st) == hipSuccess ? TSAR_OK : TSAR_ERR_HIP, nullptr);
 }

@@ -268,6 +268,7 @@ extern "C" int tsar_destroy(tsar_ctx* ctx) {
     free_views(ctx);
     free_planes(ctx);
     dev_free(ctx->dscene); dev_free(ctx->region_text); dev_free(ctx->region_size); dev_free(ctx->region_n4);
+    if (ctx->scratch.base) hipFree(ctx->scratch.base);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return TSAR_OK;

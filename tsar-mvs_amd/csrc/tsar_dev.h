@@ -82,6 +82,14 @@ struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// Device scratch of the operators that need temporaries (weak-texture detection, region RANSAC): one arena per context, grown to
+// the largest call seen and kept, so that a worker refining view after view (tsar_gipuma --all --mode=tsar) does not pay ~18
+// hipMalloc + hipFree per operator and view (26 of the 59 ms of a RANSAC call at 24 MP were these).
+struct ScratchArena {
+    char* base = nullptr;
+    size_t cap = 0;
+};
+
 struct tsar_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -113,6 +121,38 @@ struct tsar_ctx {
     unsigned long long* dbg = nullptr;   // TSAR_DEBUG_COUNTERS=1: device counters printed by tsar_destroy
     bool timing = false;
     std::vector<KernelTimer> timers;
+    ScratchArena scratch;
+};
+
+// One operator call's view of the arena: alloc() hands out 256-byte-aligned pieces; what does not fit is a plain hipMalloc for
+// this call, and the arena is re-sized to the call's total on release, so the next call of that size allocates nothing.
+struct ScratchScope {
+    tsar_ctx* ctx;
+    size_t used = 0, need = 0;
+    std::vector<void*> extra;
+    explicit ScratchScope(tsar_ctx* c) : ctx(c) {}
+    void* alloc(size_t bytes) {
+        bytes = ((bytes ? bytes : 4) + 255) & ~(size_t)255;
+        need += bytes;
+        if (used + bytes <= ctx->scratch.cap) { void* p = ctx->scratch.base + used; used += bytes; return p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        extra.push_back(p);
+        return p;
+    }
+    void release() {                       // the stream is idle (callers synchronise first)
+        for (void* p : extra) hipFree(p);
+        extra.clear();
+        if (need > ctx->scratch.cap) {
+            if (ctx->scratch.base) hipFree(ctx->scratch.base);
+            ctx->scratch.base = nullptr;
+            ctx->scratch.cap = 0;
+            void* p = nullptr;
+            if (hipMalloc(&p, need) == hipSuccess) { ctx->scratch.base = (char*)p; ctx->scratch.cap = need; }
+        }
+        used = need = 0;
+    }
+    ~ScratchScope() { release(); }
 };
 
 #define TSAR_HIP_TRY(ctx, expr)                                                                       \
