@@ -566,11 +566,13 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     m.close()
 
 
-@pytest.mark.parametrize("lookahead", ["1", "2", "3"])
-def test_ransac_regions_bit_exact(mid_scene, monkeypatch, lookahead):
-    """lookahead: how many perturbation steps of stage 2 share one pass over the points (ransac_kernels.hip); every setting
-    must replay the reference's sequential accept order exactly"""
-    monkeypatch.setenv("TSAR_RANSAC_LOOKAHEAD", lookahead)
+@pytest.mark.parametrize("knob,value", [("TSAR_RANSAC_CHAIN", "8"), ("TSAR_RANSAC_CHAIN", "4"), ("TSAR_RANSAC_CHAIN", "16"),
+                                        ("TSAR_RANSAC_LOOKAHEAD", "1"), ("TSAR_RANSAC_LOOKAHEAD", "2"), ("TSAR_RANSAC_LOOKAHEAD", "3")])
+def test_ransac_regions_bit_exact(mid_scene, monkeypatch, knob, value):
+    """how stage 2 shares passes over the points between perturbation steps (ransac_kernels.hip): a speculative chain of K steps
+    (the default, K = 8) or a tree of the accept / reject histories of G steps; every setting must replay the reference's
+    sequential accept order exactly"""
+    monkeypatch.setenv(knob, value)
     sc = mid_scene
     h, w = sc.h, sc.w
     orc, m = _prepared_pair(sc, 12)

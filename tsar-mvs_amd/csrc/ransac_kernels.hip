@@ -379,6 +379,69 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_kernel(const float* __
     }
 }
 
+// Stage 2 as a speculative CHAIN of K steps.  Measured on full-size scenes, only 1.6-2 % of the 4 000 perturbation steps are
+// accepted (and most of those at the finest scale, with an equal count), so the candidates of steps t0 .. t0 + K - 1 are all
+// built from the current best plane — what they are if none of them is accepted —, counted in ONE pass over the points, and the
+// decisions replayed in order: the first accepted step ends the pass (the later candidates started from the wrong plane) and the
+// next pass begins right after it.  Same planes, counts and decisions as the sequential loop; ~K / (1 + 0.02 K) steps per pass
+// instead of one, so the per-pass costs (two barriers, the cross-wave reduction, the perturbation) are paid ~7 times less often
+// at K = 8 and what remains is the FP64 arithmetic of the counts.
+template <int K>
+__global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
+                                                                       const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
+                                                                       uint32_t k0, uint32_t k1, uint32_t flags, const RansacState* __restrict__ state,
+                                                                       const int* __restrict__ cnt_all, float4* __restrict__ region_n4,
+                                                                       float* __restrict__ inlier_ratio) {
+    __shared__ int sh[RS_BLOCK / 64], sh2[RS_BLOCK / 64];
+    __shared__ int shb[RS_BLOCK / 64][K];
+    __shared__ double shpl[K][4];
+    const int slot = blockIdx.x;
+    const int rg = region_of_slot[slot];
+    const int n = pts_count[slot];
+    const float* __restrict__ pts = pts_all + 3 * (size_t)pts_start[slot];
+    RansacState st = state[slot];
+    if (n > 0) {
+        {   // the last phase of stage 1 still has to be replayed
+            int best_cnt;
+            const int ix = replay_phase(cnt_all + (size_t)slot * RS_PHASE, st.maximum, sh, sh2, &best_cnt);
+            if (ix >= 0) {
+                ransac_hypothesis(pts, n, rg, 9 * RS_PHASE + ix, k0, k1, flags, st.pl);
+                st.maximum = best_cnt;
+            }
+        }
+        const double depth_abs = st.depth_abs_f;
+        int t0 = 0;
+        while (t0 < 4000) {                                   // every thread carries the same t0 and state
+            const int k_here = min(K, 4000 - t0);
+            if (threadIdx.x < K) {                            // (slots beyond k_here repeat the last step: counted, never read)
+                double cand[4];
+                ransac_perturb(st.pl, t0 + min((int)threadIdx.x, k_here - 1), rg, k0, k1, cand);
+#pragma unroll
+                for (int e = 0; e < 4; e++) shpl[threadIdx.x][e] = cand[e];
+            }
+            __syncthreads();
+            int cnt[K];
+            block_count_batch<RS_BLOCK, K>(pts, n, shpl, depth_abs, shb, cnt);
+            int advance = k_here;
+#pragma unroll
+            for (int g = 0; g < K; g++) {
+                if (g < advance && cnt[g] >= st.maximum) {    // the first accepted step of the chain (main.cpp:1701: `>=`)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) st.pl[e] = shpl[g][e];
+                    st.maximum = cnt[g];
+                    advance = g + 1;
+                }
+            }
+            t0 += advance;
+            __syncthreads();                                  // shpl is rewritten by the next pass
+        }
+    }
+    if (threadIdx.x == 0) {
+        region_n4[rg] = make_float4((float)st.pl[0], (float)st.pl[1], (float)st.pl[2], (float)st.pl[3]);
+        inlier_ratio[rg] = n > 0 ? (float)st.maximum / (float)n : 0.f;
+    }
+}
+
 extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, float* inlier_ratio_out) {
     if (!ctx) return TSAR_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return TSAR_ERR_HIP; }
@@ -480,7 +543,10 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         // measured on six ~50 000-point regions: lookahead 1 / 2 / 3 -> 25.9 / 26.4 / 33.7 ms: the passes are bound by the CU's FP64
         // rate (7 operations per point and plane), not by streaming the points, so the extra planes of a lookahead cost what
         // the saved passes return.  1 is the default; 2 and 3 stay selectable (and tested) for other region sizes.
-        const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 1;
+        const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 0;
+        // default: the speculative chain (ransac_refine_chain_kernel), K = 8; TSAR_RANSAC_CHAIN=4|8|16 picks the length,
+        // TSAR_RANSAC_LOOKAHEAD=1|2|3 the history-tree kernel instead
+        const int chain = getenv("TSAR_RANSAC_CHAIN") ? atoi(getenv("TSAR_RANSAC_CHAIN")) : 8;
         {
             ScopedKernelTimer tm(ctx, "ransac_fit");
             for (int phase = 0; phase < 10; phase++) {
@@ -490,6 +556,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                                    ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, phase);
             }
             auto refine = lookahead == 1 ? ransac_refine_kernel<1> : (lookahead == 3 ? ransac_refine_kernel<3> : ransac_refine_kernel<2>);
+            if (lookahead < 1) refine = chain == 4 ? ransac_refine_chain_kernel<4> : (chain == 16 ? ransac_refine_chain_kernel<16> : ransac_refine_chain_kernel<8>);
             hipLaunchKernelGGL(refine, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->hscene.seed_lo,
                                ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio);
         }
