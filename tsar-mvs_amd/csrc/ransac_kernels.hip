@@ -127,6 +127,9 @@ DEVFN int block_count(const float* __restrict__ pts, int n, double a, double b, 
 }
 
 // The same count for NB planes in one pass over the points; pl in LDS (every thread reads all of them).
+// (Deciding the comparison in single precision with an error band and falling back to doubles inside it was built and measured:
+// bit-identical counts, no gain — a non-packed v_fma_f32 issues at the rate of v_fma_f64 on this chip, and the compares and the
+// count do not pack.)
 template <int BS, int NB>
 DEVFN void block_count_batch(const float* __restrict__ pts, int n, const double (*pl)[4], double thr, int (*shb)[NB], int* out) {
     double P[NB][4];
@@ -422,15 +425,16 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_kernel(const flo
             __syncthreads();
             int cnt[K];
             block_count_batch<RS_BLOCK, K>(pts, n, shpl, depth_abs, shb, cnt);
+            int accepted = -1, count_acc = 0;                 // the first accepted step of the chain (main.cpp:1701: `>=`)
+#pragma unroll
+            for (int g = K - 1; g >= 0; g--)
+                if (g < k_here && cnt[g] >= st.maximum) { accepted = g; count_acc = cnt[g]; }
             int advance = k_here;
+            if (accepted >= 0) {                              // (one plane read with a dynamic index, not K of them selected among)
 #pragma unroll
-            for (int g = 0; g < K; g++) {
-                if (g < advance && cnt[g] >= st.maximum) {    // the first accepted step of the chain (main.cpp:1701: `>=`)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) st.pl[e] = shpl[g][e];
-                    st.maximum = cnt[g];
-                    advance = g + 1;
-                }
+                for (int e = 0; e < 4; e++) st.pl[e] = shpl[accepted][e];
+                st.maximum = count_acc;
+                advance = accepted + 1;
             }
             t0 += advance;
             __syncthreads();                                  // shpl is rewritten by the next pass
