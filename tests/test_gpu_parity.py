@@ -567,6 +567,7 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
 
 
 @pytest.mark.parametrize("knob,value", [("TSAR_RANSAC_CHAIN", "8"), ("TSAR_RANSAC_CHAIN", "4"), ("TSAR_RANSAC_CHAIN", "16"),
+                                        ("TSAR_RANSAC_WGS", "1"), ("TSAR_RANSAC_WGS", "2"), ("TSAR_RANSAC_WGS", "4"), ("TSAR_RANSAC_WGS", "7"),
                                         ("TSAR_RANSAC_LOOKAHEAD", "1"), ("TSAR_RANSAC_LOOKAHEAD", "2"), ("TSAR_RANSAC_LOOKAHEAD", "3")])
 def test_ransac_regions_bit_exact(mid_scene, monkeypatch, knob, value):
     """how stage 2 shares passes over the points between perturbation steps (ransac_kernels.hip): a speculative chain of K steps

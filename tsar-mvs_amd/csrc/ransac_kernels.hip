@@ -446,6 +446,106 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_kernel(const flo
     }
 }
 
+// The chain again, with a region's points split over W workgroups (W CUs) instead of one.  Every workgroup carries the same
+// state and makes the same decisions; per pass each counts its share of the points, adds its K counts to the pass's accumulator
+// (three rotate: workgroup 0 clears the next one before it arrives at the barrier, a pass after its last reader left) and waits
+// at a per-region arrival counter until all W have added.  ~540 passes per region, a few microseconds of barrier each, against
+// 33 us of counting per pass on one CU.  The W workgroups of a region must be resident together: the host launches at most
+// one 1024-thread workgroup per CU, and a wait that does not end within ~2^22 polls raises `failed` (every workgroup then
+// leaves) and the host runs the single-workgroup kernel instead — a spin can never hang the device.
+// sync[slot]: [0] arrival counter, [1 .. 3 K] the three accumulators.
+#define RS_SYNC_INTS 64
+template <int K>
+__global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_mw_kernel(const float* __restrict__ pts_all, const int* __restrict__ pts_start,
+                                                                          const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
+                                                                          uint32_t k0, uint32_t k1, uint32_t flags, const RansacState* __restrict__ state,
+                                                                          const int* __restrict__ cnt_all, float4* __restrict__ region_n4,
+                                                                          float* __restrict__ inlier_ratio, int W, int* sync_all, int* failed) {
+    static_assert(1 + 3 * K <= RS_SYNC_INTS, "sync block too small");
+    __shared__ int sh[RS_BLOCK / 64], sh2[RS_BLOCK / 64];
+    __shared__ int shb[RS_BLOCK / 64][K];
+    __shared__ double shpl[K][4];
+    __shared__ int tot[K];
+    __shared__ int give_up;
+    const int slot = blockIdx.x / W, wg = blockIdx.x - slot * W;
+    const int rg = region_of_slot[slot];
+    const int n = pts_count[slot];
+    const float* __restrict__ pts = pts_all + 3 * (size_t)pts_start[slot];
+    const int i0 = (int)(((long long)n * wg) / W), i1 = (int)(((long long)n * (wg + 1)) / W);
+    int* sync = sync_all + (size_t)slot * RS_SYNC_INTS;
+    RansacState st = state[slot];
+    bool ok = true;
+    if (n > 0) {
+        {   // the last phase of stage 1 still has to be replayed (every workgroup, identically)
+            int best_cnt;
+            const int ix = replay_phase(cnt_all + (size_t)slot * RS_PHASE, st.maximum, sh, sh2, &best_cnt);
+            if (ix >= 0) {
+                ransac_hypothesis(pts, n, rg, 9 * RS_PHASE + ix, k0, k1, flags, st.pl);
+                st.maximum = best_cnt;
+            }
+        }
+        const double depth_abs = st.depth_abs_f;
+        int t0 = 0, pass = 0;
+        while (t0 < 4000 && ok) {
+            const int k_here = min(K, 4000 - t0);
+            if (threadIdx.x < K) {
+                double cand[4];
+                ransac_perturb(st.pl, t0 + min((int)threadIdx.x, k_here - 1), rg, k0, k1, cand);
+#pragma unroll
+                for (int e = 0; e < 4; e++) shpl[threadIdx.x][e] = cand[e];
+            }
+            __syncthreads();
+            int cnt[K];
+            block_count_batch<RS_BLOCK, K>(pts + 3 * (size_t)i0, i1 - i0, shpl, depth_abs, shb, cnt);
+            int* acc = sync + 1 + (pass % 3) * K;
+            int* acc_next = sync + 1 + ((pass + 1) % 3) * K;
+            if (threadIdx.x < K) {
+                int mine = 0;
+#pragma unroll
+                for (int g = 0; g < K; g++) mine = ((int)threadIdx.x == g) ? cnt[g] : mine;
+                __hip_atomic_fetch_add(&acc[threadIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wg == 0) __hip_atomic_store(&acc_next[threadIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                  // this workgroup's K additions (and the clear) are issued
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const int want = W * (pass + 1);
+                int polls = 0, bad = 0;
+                while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((++polls & 1023) == 0 && __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = 1; break; }
+                    if (polls > (1 << 22)) { __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
+                }
+                give_up = bad;
+            }
+            __syncthreads();
+            if (give_up) { ok = false; break; }
+            if (threadIdx.x < K) tot[threadIdx.x] = __hip_atomic_load(&acc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            int accepted = -1, count_acc = 0;                 // the first accepted step of the chain (main.cpp:1701: `>=`)
+#pragma unroll
+            for (int g = K - 1; g >= 0; g--) {
+                const int c = tot[g];
+                if (g < k_here && c >= st.maximum) { accepted = g; count_acc = c; }
+            }
+            int advance = k_here;
+            if (accepted >= 0) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) st.pl[e] = shpl[accepted][e];
+                st.maximum = count_acc;
+                advance = accepted + 1;
+            }
+            t0 += advance;
+            pass++;
+            __syncthreads();                                  // shpl / tot are rewritten by the next pass
+        }
+    }
+    if (threadIdx.x == 0 && wg == 0 && ok) {
+        region_n4[rg] = make_float4((float)st.pl[0], (float)st.pl[1], (float)st.pl[2], (float)st.pl[3]);
+        inlier_ratio[rg] = n > 0 ? (float)st.maximum / (float)n : 0.f;
+    }
+}
+
 extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, float* inlier_ratio_out) {
     if (!ctx) return TSAR_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return TSAR_ERR_HIP; }
@@ -544,9 +644,9 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         RansacState* d_state = (RansacState*)dmalloc((size_t)nslot * sizeof(RansacState));
         int* d_cnt = (int*)dmalloc((size_t)nslot * RS_PHASE * sizeof(int));
         if (!d_state || !d_cnt) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
-        // measured on six ~50 000-point regions: lookahead 1 / 2 / 3 -> 25.9 / 26.4 / 33.7 ms: the passes are bound by the CU's FP64
-        // rate (7 operations per point and plane), not by streaming the points, so the extra planes of a lookahead cost what
-        // the saved passes return.  1 is the default; 2 and 3 stay selectable (and tested) for other region sizes.
+        // stage 2, measured on six ~50 000-point regions: the history tree with lookahead 1 / 2 / 3 -> 25.9 / 26.4 / 33.7 ms (the passes
+        // are bound by the CU's FP64 rate, so the extra planes of a tree cost what the saved passes return); the speculative chain of
+        // 8 steps 17.5 ms; the chain on 8 CUs per region 5.3 ms (the default).
         const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 0;
         // default: the speculative chain (ransac_refine_chain_kernel), K = 8; TSAR_RANSAC_CHAIN=4|8|16 picks the length,
         // TSAR_RANSAC_LOOKAHEAD=1|2|3 the history-tree kernel instead
@@ -561,8 +661,29 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
             }
             auto refine = lookahead == 1 ? ransac_refine_kernel<1> : (lookahead == 3 ? ransac_refine_kernel<3> : ransac_refine_kernel<2>);
             if (lookahead < 1) refine = chain == 4 ? ransac_refine_chain_kernel<4> : (chain == 16 ? ransac_refine_chain_kernel<16> : ransac_refine_chain_kernel<8>);
-            hipLaunchKernelGGL(refine, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->hscene.seed_lo,
-                               ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio);
+            // W workgroups (CUs) per region in stage 2 (ransac_refine_chain_mw_kernel): 8 by default (measured on five ~50 000-point
+            // regions: W = 1 / 2 / 4 / 8 / 16 -> 17.5 / 10.8 / 6.9 / 5.3 / 4.8 ms for the whole fit), at most one workgroup per CU so
+            // that all of them are resident together; TSAR_RANSAC_WGS=W overrides, 1 = the single-workgroup kernel
+            int wgs = getenv("TSAR_RANSAC_WGS") ? atoi(getenv("TSAR_RANSAC_WGS")) : 8;
+            int n_cu = 0;
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) n_cu = 0;
+            if (wgs > n_cu / (nslot > 0 ? nslot : 1)) wgs = n_cu / (nslot > 0 ? nslot : 1);
+            bool fitted = false;
+            if (lookahead < 1 && wgs >= 2) {
+                int* d_sync = (int*)dmalloc((size_t)nslot * RS_SYNC_INTS * 4 + 4);
+                if (!d_sync) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
+                int* d_failed = d_sync + (size_t)nslot * RS_SYNC_INTS;
+                hipMemsetAsync(d_sync, 0, (size_t)nslot * RS_SYNC_INTS * 4 + 4, st);
+                hipLaunchKernelGGL(ransac_refine_chain_mw_kernel<8>, dim3(nslot * wgs), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot,
+                                   ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio, wgs, d_sync, d_failed);
+                int h_failed = 1;
+                hipMemcpyAsync(&h_failed, d_failed, 4, hipMemcpyDeviceToHost, st);
+                if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "ransac kernel failed");
+                fitted = h_failed == 0;                       // else: the workgroups were not resident together; one per region below
+            }
+            if (!fitted)
+                hipLaunchKernelGGL(refine, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->hscene.seed_lo,
+                                   ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio);
         }
         if (hipGetLastError() != hipSuccess) return done(TSAR_ERR_HIP, "ransac launch failed");
         TR("fit");
