@@ -470,10 +470,10 @@ int main(int argc, char** argv) {
                 tsar_ctx* worker_ctx = nullptr;
                 host_result[0].shared_ctx = host_result[1].shared_ctx = &worker_ctx;
                 std::future<bool> writing[2];
-                // refinement modes: a ring of (page-locked) input buffers; the maps, weak.png and reference image of the next three
+                // refinement modes: a ring of (page-locked) input buffers; the maps, weak.png and reference image of the next seven
                 // views are read while view k is on the GPU (one weak.png inflates in ~0.3 s, a view's kernels take ~0.1 s)
                 const bool external = o.mode == "load" || o.mode == "tsar";
-                constexpr size_t RING = 4;
+                constexpr size_t RING = 8;
                 ExternalInputs inputs[RING];
                 for (auto& in : inputs) in.pinned = true;
                 auto view_dir = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d", ref); return o.mslp_folder + "APD/" + b + "/"; };
