@@ -171,6 +171,41 @@ def test_cfg2_fast_run_vs_strict_full_size():
     assert abs(agree["median_normal_error_deg_fast"] - agree["median_normal_error_deg_strict"]) < 0.05 * max(1.0, agree["median_normal_error_deg_strict"]), agree
 
 
+@pytest.mark.parametrize("box,n_best", [(19, 2), (7, 1), (15, 3)])
+def test_other_windows_fast_run_vs_strict(box, n_best):
+    """the general-window tap loop (pm_core_lut.h; box 19 / n_best 2 are the reference binary's defaults) at run level: fast vs
+    strict (= oracle-exact) on the GPU, same seed, with the reseeded strict run as the control"""
+    w, h, n = 2016, 1344, 6
+    sc = synth.make_scene(w, h, n, device="cuda", seed=77)
+    dev = torch.device("cuda")
+    maps = {}
+    for name, flags, seed in (("strict", api.FLAG_STRICT_DIV, 2024), ("fast", 0, 2024), ("strict_reseeded", api.FLAG_STRICT_DIV, 2025)):
+        m = api.matcher_from_scene(sc, box=box, n_best=n_best, seed=seed, flags=flags)
+        depth = torch.empty((h, w), dtype=torch.float32, device=dev)
+        normal = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+        cost = torch.empty((h, w), dtype=torch.float32, device=dev)
+        m.pm_init()
+        m.pm_iterate(6)
+        m.compute_disp()
+        m.get_result_device(depth=depth, normal=normal, cost=cost)
+        m.close()
+        maps[name] = (depth, normal, float(cost.mean()))
+    agree = _agreement(maps["fast"][0], maps["fast"][1], maps["strict"][0], maps["strict"][1])
+    control = _agreement(maps["strict_reseeded"][0], maps["strict_reseeded"][1], maps["strict"][0], maps["strict"][1])
+    gt = sc.gt_depth
+    for tag, (d, nrm, mc) in maps.items():
+        agree[f"gt_1pct_{tag}"] = float(((d - gt).abs() / gt < 0.01).float().mean())
+        agree[f"mean_cost_{tag}"] = mc
+    agree["control_strict_vs_strict_reseeded"] = control
+    _record(f"box{box}_nbest{n_best}_fast_vs_strict_{w}x{h}_{n}views_6iters", agree)
+    _better_than_control(agree, control)
+    # f = 1129 px here: a 1e-3 depth change is 0.011 px of disparity (between cfg1's 0.004 and cfg2's 0.034)
+    assert agree["depth_within_1e-3"] >= 0.98 and agree["depth_within_1e-2"] >= 0.9995, agree      # measured 0.990 / 0.9989 / 0.9993 and 0.9999+
+    assert agree["valid_mismatch"] < 1e-3, agree
+    assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_strict"]) < 2e-3, agree
+    assert abs(agree["mean_cost_fast"] - agree["mean_cost_strict"]) < 1e-4, agree
+
+
 @pytest.mark.parametrize("colour", [0, 1])
 def test_diverged_pixels_are_valid_patchmatch_steps(mid_scene, colour):
     """(c) one fast half-sweep from the oracle's state; where it lands on another plane than the oracle, the ORACLE's score of
