@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--workers", type=int, nargs="+", default=[1, 2])
+    ap.add_argument("--fuse", action="store_true", help="also fuse the views in the same process (--all --fuse): matched maps -> APD/APD_TSAR.ply")
+    ap.add_argument("--fusion-cli", action="store_true", dest="fusion_cli", help="then run the separate tsar_fusion tool on the written .dmb files")
     args = ap.parse_args()
     import torch
     dev = "cuda" if torch.cuda.is_available() else "cpu"
@@ -37,7 +39,7 @@ def main():
         for wk in args.workers:
             t0 = time.perf_counter()
             out = subprocess.run([cli, "--all", "--gpus=1", f"--workers={wk}", "-mslp_folder", root, "-images_folder", root + "images/",
-                                  f"--iterations={args.iters}", "--blocksize=11", "--n_best=1"], capture_output=True, text=True)
+                                  f"--iterations={args.iters}", "--blocksize=11", "--n_best=1", *(["--fuse"] if args.fuse else [])], capture_output=True, text=True)
             dt = time.perf_counter() - t0
             ok = out.returncode == 0 and all(os.path.exists(root + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(args.views))
             mp = args.width * args.height * args.views / dt / 1e6
@@ -47,6 +49,18 @@ def main():
                 print(out.stdout[-2000:], out.stderr[-2000:])
             else:
                 print("   " + " | ".join(l for l in out.stdout.splitlines() if l.startswith("view"))[:600])
+                for l in out.stdout.splitlines():
+                    if l.startswith("fused"):
+                        print("   " + l)
+        if args.fusion_cli:
+            t0 = time.perf_counter()
+            out = subprocess.run([os.path.join(ROOT, "tsar-mvs_amd", "tsar_fusion"), root, "--num_consistent=2", "--reproj_error=2", "--depth_diff=0.01", "--angle=15"],
+                                 capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            print(f"tsar_fusion over the {args.views} views' .dmb files: {dt:.2f} s, rc {out.returncode}", flush=True)
+            print("   " + " | ".join(out.stdout.strip().splitlines()[-4:])[:600])
+            if out.returncode != 0:
+                print(out.stderr[-1500:])
 
 
 if __name__ == "__main__":

@@ -561,14 +561,14 @@ int main(int argc, char** argv) {
             }
             if (idx.empty()) idx.push_back(0);
             const int64_t cap = (int64_t)n * fw * fh;
-            std::vector<float> pts((size_t)cap * 9);
+            std::unique_ptr<float[]> pts(new float[(size_t)cap * 9]);   // not zero-filled: only the fused points' pages are ever touched
             int64_t cnt = 0;
-            const int rc = tsar_fuse(0, n, fw, fh, cams.data(), pd.data(), pn.data(), pg.data(), TSAR_MEM_DEVICE, off.data(), idx.data(), &o.fusion, pts.data(), cap, &cnt);
+            const int rc = tsar_fuse(0, n, fw, fh, cams.data(), pd.data(), pn.data(), pg.data(), TSAR_MEM_DEVICE, off.data(), idx.data(), &o.fusion, pts.get(), cap, &cnt);
             release();
             if (rc != TSAR_OK) { fprintf(stderr, "tsar_fuse failed: %d\n", rc); return 1; }
             if (cnt > cap) cnt = cap;
             const std::string out = o.mslp_folder + "APD/APD_TSAR.ply";
-            if (!write_cloud_ply(out, pts.data(), cnt)) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+            if (!write_cloud_ply(out, pts.get(), cnt)) { fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
             const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             printf("fused %d views on gpu 0: %lld points -> %s (gather of %.1f MB from other gpus + uploads %.3f s, total %.3f s)\n", n, (long long)cnt, out.c_str(),
                    moved / 1e6, t_gather, t_all);

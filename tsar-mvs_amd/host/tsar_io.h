@@ -278,15 +278,22 @@ static bool write_cloud_ply(const std::string& path, const float* pts, int64_t n
     if (!f) return false;
     fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\n"
                "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", (long long)n);
-    for (int64_t i = 0; i < n; i++) {
-        const float* p = pts + 9 * i;
-        fwrite(p, sizeof(float), 6, f);
-        float g = p[6] < 0 ? 0 : (p[6] > 255 ? 255 : p[6]);
-        const unsigned char c = (unsigned char)(g + 0.5f);
-        const unsigned char rgb[3] = {c, c, c};
-        fwrite(rgb, 1, 3, f);
+    // 27-byte records assembled a megapoint at a time: one fwrite per chunk instead of two per point
+    const int64_t chunk = 1 << 20;
+    std::vector<unsigned char> rec((size_t)chunk * 27);
+    bool ok = true;
+    for (int64_t i0 = 0; i0 < n && ok; i0 += chunk) {
+        const int64_t m = n - i0 < chunk ? n - i0 : chunk;
+        for (int64_t i = 0; i < m; i++) {
+            const float* p = pts + 9 * (i0 + i);
+            unsigned char* o = rec.data() + 27 * i;
+            memcpy(o, p, 24);
+            const float g = p[6] < 0 ? 0 : (p[6] > 255 ? 255 : p[6]);
+            o[24] = o[25] = o[26] = (unsigned char)(g + 0.5f);
+        }
+        ok = fwrite(rec.data(), 27, (size_t)m, f) == (size_t)m;
     }
     fclose(f);
-    return true;
+    return ok;
 }
 
