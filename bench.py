@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--box", type=int, default=11)
     ap.add_argument("--n_best", type=int, default=1)
+    ap.add_argument("--texture-filter-8bit", action="store_true", dest="tex8",
+                    help="bilinear weights with 8 fractional bits like the CUDA texture unit (TSAR_FLAG_TEX_FILTER_8BIT); not the headline configuration")
     ap.add_argument("--cam-step", type=float, default=0.03, dest="cam_step")
     ap.add_argument("--cpu-width", type=int, default=960, dest="cpu_width")
     ap.add_argument("--cpu-height", type=int, default=640, dest="cpu_height")
@@ -225,7 +227,7 @@ def main():
 
     # each rank owns one reference view of the scene (its own camera arc position), SURVEY §8(e)
     sc = synth.make_scene(args.width, args.height, args.views, device=dev, seed=1234, cam_seed=42 + rank, step=args.cam_step)
-    m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024 + rank, device=local_rank)
+    m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024 + rank, device=local_rank, flags=api.FLAG_TEX_FILTER_8BIT if args.tex8 else 0)
     w, h = args.width, args.height
     # Two sets of result buffers: the gather of step k (RCCL, asynchronous, on the collective's own stream) runs while the
     # kernels of step k+1 fill the other set; a set is reused only after its gather has completed.
@@ -313,7 +315,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ETH3D-size view {w}x{h}, 1 ref + {args.views} src views, {args.iters} PatchMatch iters, box {args.box}, n_best {args.n_best}; one ref view per GPU",
-                       "mode": "fast",      # default arithmetic of the library and CLI; tolerance vs the oracle: tests/test_gpu_fast_mode.py; "strict" below = oracle-exact
+                       "mode": "fast" if not args.tex8 else "fast + 8-bit texture filter",      # default arithmetic of the library and CLI; tolerance vs the oracle: tests/test_gpu_fast_mode.py; "strict" below = oracle-exact
                        "width": w, "height": h, "src_views": args.views, "iters": args.iters, "frac_depth_within_1pct_of_gt": round(frac_ok, 4)},
         }
         if "pm_sweep" in timing and timing["pm_sweep"][0] > 0:

@@ -104,7 +104,8 @@ extern "C" {
 #define TSAR_FLAG_TEX_FILTER_8BIT    (1u << 5) /* bilinear fractions rounded to 8 fractional bits before the blend, as the CUDA
                                                   texture unit the reference samples through stores them (linear filtering with
                                                   1.8 fixed-point weights, main.cpp:1215-1219); the unit's rounding rule is
-                                                  unpublished: round-to-nearest-even here.  Runs the generic kernels (slower). */
+                                                  unpublished: round-to-nearest-even here.  Runs the general-window tap loop at every box
+                                                  (box 11: ~15 % below the default filter). */
 
 typedef struct tsar_ctx tsar_ctx;
 
@@ -119,8 +120,8 @@ typedef struct tsar_camera {
 /* Subset of the reference's AlgorithmParameters (algorithmparameters.h:54-88) that the GPU path
  * reads.  Zero-initialise, then tsar_default_params(). */
 typedef struct tsar_params {
-    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19).  1..63; images that are not an 8-bit decode (and
-                             TSAR_FLAG_TEX_FILTER_8BIT): tsar_set_views refuses boxes whose per-thread weight table exceeds
+    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19).  1..63; images that are not an 8-bit decode:
+                             tsar_set_views refuses boxes whose per-thread weight table exceeds
                              the LDS (largest square box 23) */
     int32_t box_vsize;
     int32_t n_best;       /* --n_best (scripts 1; default 2) */

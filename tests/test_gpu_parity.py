@@ -78,17 +78,18 @@ def test_cost_planes_fast_tolerance(small_scene, box, n_best):
     m.close()
 
 
-def test_8bit_texture_filter_mode_bit_exact(small_scene):
+@pytest.mark.parametrize("box,n_best", [(11, 1), (19, 2), (7, 3), (13, 5)])
+def test_8bit_texture_filter_mode_bit_exact(small_scene, box, n_best):
     """TSAR_FLAG_TEX_FILTER_8BIT (S3'): the CUDA texture unit's 8-fractional-bit filter weights; strict arithmetic, whole
-    iterations and the reverse-direction cost"""
+    iterations and the reverse-direction cost.  The mode runs the general-window tap loop at every box (11 included)."""
     sc = small_scene
     fl = api.FLAG_TEX_FILTER_8BIT
-    orc = _oracle(sc, seed=41, flags=fl)
+    orc = _oracle(sc, seed=41, flags=fl, box=box, n_best=n_best)
     orc.pm_init()
     orc.pm_iterate(2)
     orc.lrdiff_op()
     orc.getview()
-    m = api.matcher_from_scene(sc, seed=41, flags=fl | api.FLAG_STRICT_DIV)
+    m = api.matcher_from_scene(sc, seed=41, flags=fl | api.FLAG_STRICT_DIV, box=box, n_best=n_best)
     m.pm_init()
     m.pm_iterate(2)
     planes, cost, bv, _ = m.get_plane()
@@ -98,14 +99,16 @@ def test_8bit_texture_filter_mode_bit_exact(small_scene):
     m.compute_disp()
     assert np.array_equal(m.get_result(("confid",))["confid"], orc.confid)
     m.close()
-    plain = _oracle(sc, seed=41)
+    plain = _oracle(sc, seed=41, box=box, n_best=n_best)
     plain.pm_init()
     plain.pm_iterate(2)
     assert not np.array_equal(plain.c, orc.c)              # the mode does change the numbers
-    f = api.matcher_from_scene(sc, seed=41, flags=fl)        # fast arithmetic + 8-bit filter: within the fast-mode cost tolerance
+    f = api.matcher_from_scene(sc, seed=41, flags=fl, box=box, n_best=n_best)        # fast arithmetic + 8-bit filter: within the fast-mode cost tolerance
     c_fast, _, _ = f.pm_cost_planes(orc.norm4.copy())
     f.close()
-    assert np.max(np.abs(c_fast - orc.c)) <= 1e-3
+    # (a tap whose fraction sits on a rounding boundary of the 1/256 grid may land on the neighbouring step under the fast
+    # mode's ~1-ulp different position: the cost then moves by one quantisation step of one tap, measured max 1.1e-3)
+    assert np.max(np.abs(c_fast - orc.c)) <= 2e-3 and np.percentile(np.abs(c_fast - orc.c), 99) <= 2e-4
 
 
 def test_float_image_path_matches_quad_path(small_scene):

@@ -111,6 +111,7 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     const float cen = tile_value(tile[own]);
     const float fa = (float)(ROW ? x : y), fl = (float)(ROW ? y : x);
     const float uhi = (float)(w - 1), vhi = (float)(h - 1);
+    const bool q8 = (sc->flags & TSAR_FLAG_TEX_FILTER_8BIT) != 0;   // bilinear weights with 8 fractional bits (wave-uniform)
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     // rows: the table rows of this chunk's taps (scalars, loaded while the previous chunk ran)
     auto chunk = [&](const unsigned short* trow, const uint32_t (&rows)[CH], int c0, float bx, float by, float bz, auto clamp_tag) {
@@ -169,6 +170,13 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
         if constexpr (ROW) lut_wait_lds<CH>(r, off_last);
 #pragma unroll
         for (int jj = 0; jj < CH; jj++) wv[jj] = lut_weight(lut, rows[jj], r[jj], cen);
+        if (q8) {                                           // one scalar branch per chunk; the oracle's rounding (sample_bilinear, pm_core.h)
+#pragma unroll
+            for (int jj = 0; jj < CH; jj++) {
+                ax[jj] = rintf(ax[jj] * 256.0f) * 0.00390625f;
+                ay[jj] = rintf(ay[jj] * 256.0f) * 0.00390625f;
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);                  // nothing of phase 3 may move above the last gather
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);

@@ -108,7 +108,8 @@ int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const Pl
     const bool r5 = hs.hrad == 5 && hs.vrad == 5;
     // 8-bit imagery, any window but the box-11 / two-best-views configuration (which has its own tap loop): shared weight
     // table, chunked lines (pm_sweep_lut.hip)
-    const bool own_loop = r5 && need <= 4 && (need <= 2 || ctx->variant == 250 || ctx->variant == 122);
+    // (the box-11 loop filters with exact fp32 weights only: the 8-bit filter mode takes the general-window loop at box 11 too)
+    const bool own_loop = r5 && need <= 4 && (need <= 2 || ctx->variant == 250 || ctx->variant == 122) && !(hs.flags & TSAR_FLAG_TEX_FILTER_8BIT);
     if (lut_path_applies(ctx) && (!own_loop || lut_path_forced())) return launch_pm_sweep_lut(ctx, need, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     if (need <= 4 && need > 2 && r5) return launch_sweep_nh<4, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     if (need <= 2) return r5 ? launch_sweep_nh<2, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)

@@ -362,11 +362,11 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     derive_cameras(ctx, cams);
     fill_scene_params(ctx);
     if (!lut_path_applies(ctx)) {
-        // float imagery (and the 8-bit-filter mode) keeps the hoisted bilateral weights per thread in LDS, (hrad+1)(vrad+1) taps x
+        // float imagery keeps the hoisted bilateral weights per thread in LDS, (hrad+1)(vrad+1) taps x
         // 256 threads x 4 B beside the reference window; 8-bit imagery shares one table per workgroup (pm_core_lut.h): any box
         const size_t lds = (size_t)(sc.hrad + 1) * (sc.vrad + 1) * 1024 + (size_t)(32 + 2 * sc.hrad) * (16 + 2 * sc.vrad) * 4 + 16;
         if (lds > 160 * 1024)
-            return fail(ctx, TSAR_ERR_INVALID, "box too large for images that are not 8-bit (or with TSAR_FLAG_TEX_FILTER_8BIT): the per-thread weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
+            return fail(ctx, TSAR_ERR_INVALID, "box too large for images that are not 8-bit: the per-thread weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
     }
     sc.n_sel = std::min(n_views - 1, TSAR_MAX_SELECTED);   // default subset: the first 32 source views at most (tsar_set_view_subset picks others)
     for (int i = 0; i < sc.n_sel; i++) sc.sel[i] = i + 1;

@@ -183,7 +183,7 @@ int launch_pm_sweep_lut(tsar_ctx* ctx, int need, int colour, const PlaneBuf& sam
                         int do_prop, int do_refine);       // pm_sweep_lut.hip
 int launch_pm_full_lut(tsar_ctx* ctx, int need, bool init, const float4* planes, float* c, float4* n, int32_t* bv, float* rt);   // pm_init_lut.hip
 int lut_chunk_taps(int taps_per_line);
-// the general-window tap loop serves 8-bit imagery (quad textures) with exact-fp32 filtering whose window has few enough
+// the general-window tap loop serves 8-bit imagery (quad textures), both filter modes, whose window has few enough
 // distance classes for the LDS table; TSAR_LUT=0 switches it off (the one-tap-at-a-time loop then runs), TSAR_LUT=2 also sends
 // the box-11 / two-best-views configuration through it instead of its own tap loop: A/B measurements
 static inline bool lut_path_forced() {
@@ -196,7 +196,7 @@ static inline bool lut_path_applies(const tsar_ctx* ctx) {
     // (its fast-mode loop loads window texels with ds_read_u16_d16_hi: only where tsar_create's probe found the register's
     // other half zeroed — variant bit 3)
     const bool d16_ok = (hs.flags & TSAR_FLAG_STRICT_DIV) || (ctx->variant & 8);
-    return !off && d16_ok && hs.use_quad && hs.lut_classes > 0 && !(hs.flags & TSAR_FLAG_TEX_FILTER_8BIT);
+    return !off && d16_ok && hs.use_quad && hs.lut_classes > 0;
 }
 int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                         int do_prop, int do_refine, int* launched);
