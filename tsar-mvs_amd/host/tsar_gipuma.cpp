@@ -26,6 +26,7 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <fstream>
 #include <future>
@@ -473,8 +474,10 @@ int main(int argc, char** argv) {
                 // refinement modes: a ring of (page-locked) input buffers; the maps, weak.png and reference image of the next seven
                 // views are read while view k is on the GPU (one weak.png inflates in ~0.3 s, a view's kernels take ~0.1 s)
                 const bool external = o.mode == "load" || o.mode == "tsar";
-                constexpr size_t RING = 8;
-                ExternalInputs inputs[RING];
+                // (about sixteen sets in flight per process: eight with one worker, two per worker on an 8-GPU node — each set
+                // page-locks 0.39 GB at ETH3D size, and the inflates run on as many host threads)
+                const size_t RING = std::max<size_t>(2, std::min<size_t>(8, 16 / (size_t)nthr));
+                std::vector<ExternalInputs> inputs(RING);
                 for (auto& in : inputs) in.pinned = true;
                 auto view_dir = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d", ref); return o.mslp_folder + "APD/" + b + "/"; };
                 auto ref_image = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d.pgm", ref); return o.images_folder + pnm_name(b, o.color ? ".ppm" : ".pgm"); };
