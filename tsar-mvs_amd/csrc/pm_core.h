@@ -85,9 +85,9 @@ __host__ __device__ constexpr size_t tile_bytes(int tw, int th) {
 }
 
 // pad_rows: rows staged below the window (clamp addressing, so finite texels): pm_core_lut.h reads past a row's end
-template <int RH, typename TileT, int BLK = PM_BLOCK>
+template <int RH, typename TileT, int BLK = PM_BLOCK, int RW = PM_RW>
 DEVFN void stage_ref_tile(const DevScene* __restrict__ sc, TileT* tile, int x0, int y0, int hr, int vr, int pad_rows = 0) {
-    const int tw = PM_RW + 2 * hr, th = RH + 2 * vr + pad_rows;
+    const int tw = RW + 2 * hr, th = RH + 2 * vr + pad_rows;
     const global_f32_ptr img = (global_f32_ptr)sc->view[0].img;
     const int w = sc->w, h = sc->h;
     for (int k = threadIdx.x; k < tw * th; k += BLK) {

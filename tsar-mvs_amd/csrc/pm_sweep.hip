@@ -70,6 +70,9 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
                 case 250: return launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
                 case 762: return launch_sweep_t<2, 5, false, true, 762>(ctx, colour, a, b, c, sid, dp, dr);
+                case 65786: return launch_sweep_t<2, 5, false, true, 65786>(ctx, colour, a, b, c, sid, dp, dr);   // 250 + 64 x 8 region: 2 x 32 lanes per wave
+                case 16634: return launch_sweep_t<2, 5, false, true, 16634>(ctx, colour, a, b, c, sid, dp, dr);   // 250 + 8 x 8 lanes per wave
+                case 33018: return launch_sweep_t<2, 5, false, true, 33018>(ctx, colour, a, b, c, sid, dp, dr);   // 250 + 16 x 4 lanes per wave
                 case 506: return launch_sweep_t<2, 5, false, true, 506>(ctx, colour, a, b, c, sid, dp, dr);
                 case 2: return launch_sweep_t<2, 5, false, true, 2>(ctx, colour, a, b, c, sid, dp, dr);
                 case 6: return launch_sweep_t<2, 5, false, true, 6>(ctx, colour, a, b, c, sid, dp, dr);
