@@ -153,6 +153,8 @@ DEVFN PixelRef hoist_reference(const TileT* tile, int tw, int own, float* wts, i
 //          fast mode only; strict keeps the oracle's column order.
 //   bit 8: experiment (wrong results): the instruction mix of pairing two taps into one 16-byte gather
 //   bit 9: radius 5, with bits 3 and 6 — gathers of line t+1 issued before line t is blended (two register sets)
+//   bit 17: with bit 6 — gathers as structured buffer loads (idxen, stride 4): the addresser scales the element index, the per-tap
+//           shift goes away (-0.65 %); issued by asm, so their vmcnt waits are written out
 //   bit 10: any window, 8-bit imagery — view_cost_lut (pm_core_lut.h) instead of this function; bits 11-13 = taps per chunk
 // BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread])
 template <int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
@@ -196,6 +198,20 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qa);
         qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32));
         asm volatile("" : "+s"(qb_lo), "+s"(qb_hi));
+    }
+    // variant bit 17 (with bit 6; production since round 2): the gather is a structured buffer load (buffer_load_dword ... idxen) through a
+    // resource descriptor of stride 4 — the texture addresser multiplies the element index, so the per-tap shift goes away
+    // (one VALU instruction of ~26).  The loads are issued by asm (no compiler builtin reaches idxen), so their vmcnt waits are
+    // written out in phase 3.
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s rsrc = {0u, 0u, 0u, 0u};
+    if (V & 131072) {
+        const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)qorg;
+        rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)qa);
+        rsrc.y = __builtin_amdgcn_readfirstlane(((uint32_t)(qa >> 32) & 0xffffu) | (4u << 16));      // base[47:32] | stride 4
+        rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)(qp * (h + 1) - 1));                       // records from entry (1, 1) on
+        rsrc.w = 0x00020000u;                                                                         // 32-bit data format (gfx9 family)
+        asm volatile("" : "+s"(rsrc));
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     constexpr bool ROW = (V & 128) && !STRICT;     // bit 7: `i` below is then the row offset and the six taps run along x
@@ -273,7 +289,9 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
             uint32_t off = 0;
             if (!(V & 64)) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
-            if (V & 64) {                                       // base already holds the border offset: the byte offset is a plain shift
+            if (V & 131072) {
+                asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
+            } else if (V & 64) {                                // base already holds the border offset: the byte offset is a plain shift
                 const uint32_t off2 = (uint32_t)lin << 2;
                 if ((V & 256) && (jj & 1)) {
                     // EXPERIMENT (TSAR_VARIANT=506, wrong results): the upper bound of pairing two taps of a row into one wide gather
@@ -294,6 +312,17 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;                           // the four texels: one convert each, no shifts/masks
+            if (V & 131072) {
+                // the asm-issued gathers return in order: tap jj has 5 - jj behind it.  Not volatile (a volatile wait is
+                // scheduled with the loads, ahead of every blend); the q[5] input keeps each wait behind the issue of the last load, the
+                // accumulator behind the previous tap's blend
+                if (jj == 0) asm("s_waitcnt vmcnt(5)" : "+v"(q[0]) : "v"(q[5]));
+                if (jj == 1) asm("s_waitcnt vmcnt(4)" : "+v"(q[1]), "+v"(sum_src_src) : "v"(q[5]));
+                if (jj == 2) asm("s_waitcnt vmcnt(3)" : "+v"(q[2]), "+v"(sum_src_src) : "v"(q[5]));
+                if (jj == 3) asm("s_waitcnt vmcnt(2)" : "+v"(q[3]), "+v"(sum_src_src) : "v"(q[5]));
+                if (jj == 4) asm("s_waitcnt vmcnt(1)" : "+v"(q[4]), "+v"(sum_src_src) : "v"(q[5]));
+                if (jj == 5) asm("s_waitcnt vmcnt(0)" : "+v"(q[5]), "+v"(sum_src_src));
+            }
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));

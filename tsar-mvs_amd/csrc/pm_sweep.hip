@@ -49,6 +49,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
         if (const char* e = getenv("TSAR_BLOCK")) small = atoi(e) == 128;
         if (small && (ctx->variant == 250 || ctx->variant == 122)) {
             if (strict) return launch_sweep_t<2, 5, true, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
+            if (ctx->variant == 250 && ctx->buffer_gather) return launch_sweep_t<2, 5, false, true, 131322, 128>(ctx, colour, a, b, c, sid, dp, dr);
             return ctx->variant == 250 ? launch_sweep_t<2, 5, false, true, 250, 128>(ctx, colour, a, b, c, sid, dp, dr)
                                        : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
         }
@@ -67,7 +68,9 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             switch (ctx->variant) {
                 case 122: return launch_sweep_t<2, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
                 case 114: return launch_sweep_t<2, 5, false, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
-                case 250: return launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
+                case 250:       // (+ bit 17: the gathers as structured buffer loads, -0.65 %; TSAR_BUFFER_GATHER=0 keeps global loads)
+                    return ctx->buffer_gather ? launch_sweep_t<2, 5, false, true, 131322>(ctx, colour, a, b, c, sid, dp, dr)
+                                              : launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
                 case 762: return launch_sweep_t<2, 5, false, true, 762>(ctx, colour, a, b, c, sid, dp, dr);
                 case 65786: return launch_sweep_t<2, 5, false, true, 65786>(ctx, colour, a, b, c, sid, dp, dr);   // 250 + 64 x 8 region: 2 x 32 lanes per wave
@@ -89,6 +92,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     // box 11 with three or four best views: the same tap loop, four-register selection (256-thread workgroups only)
     if (quad && NB == 4 && HR == 5 && !(ctx->hscene.flags & TSAR_FLAG_TEX_FILTER_8BIT) && (ctx->variant == 250 || ctx->variant == 122)) {
         if (strict) return launch_sweep_t<4, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+        if (ctx->variant == 250 && ctx->buffer_gather) return launch_sweep_t<4, 5, false, true, 131322>(ctx, colour, a, b, c, sid, dp, dr);
         return ctx->variant == 250 ? launch_sweep_t<4, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr)
                                    : launch_sweep_t<4, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
     }

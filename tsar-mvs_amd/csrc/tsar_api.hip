@@ -235,6 +235,7 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
 #endif
     ctx->variant = probe_d16_hi_zeroes(ctx) ? 250 : 114;
     if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
+    if (const char* e = getenv("TSAR_BUFFER_GATHER")) ctx->buffer_gather = e[0] != '0';
     if (const char* e = getenv("TSAR_STRIP")) ctx->strip_w = atoi(e);
     if (const char* e = getenv("TSAR_DEBUG_COUNTERS"))
         if (e[0] == '1' && hipMalloc((void**)&ctx->dbg, 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(ctx->dbg, 0, 8 * sizeof(unsigned long long));

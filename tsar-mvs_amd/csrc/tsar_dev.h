@@ -116,6 +116,7 @@ struct tsar_ctx {
     // timing
     bool lds_sweep = false;      // TSAR_LDS_SWEEP=1: LDS-patch form of the sweep (pm_sweep_lds.hip); bit-exact, not yet faster
     int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); tsar_create picks 250 (med3/fract + D16 window loads + clamp-free loop for in-image windows + wave priority + SGPR-pinned texture base and line-top weight loads + row-wise window walk in fast mode; strict mode runs it as 122, the oracle's column order) when the D16 probe passes, else 114
+    bool buffer_gather = true;   // TSAR_BUFFER_GATHER=0: the fast tap loop's gathers as global loads + a shift instead of structured buffer loads
     int strip_w = -1;            // TSAR_STRIP=n: width in tiles of the strips the sweep walks (pm_core.h strip_tile), 0 = row-major,
                                  // -1 = automatic: one vertical band of the image per XCD (see strip_width)
     unsigned long long* dbg = nullptr;   // TSAR_DEBUG_COUNTERS=1: device counters printed by tsar_destroy
