@@ -527,7 +527,7 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
     for (int i = 0; i < num; i++) {
         const int vi = sc->sel[i];
         float c;
-        if constexpr ((V & 1024) != 0) c = view_cost_lut<STRICT, (V >> 11) & 7>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        if constexpr ((V & 1024) != 0) c = view_cost_lut<STRICT, (V >> 11) & 7, (V & 131072) != 0 && !STRICT>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         else c = view_cost<HR, STRICT, QUAD, V, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;
         if (c <= cmin) { cmin = c; bv = vi; }   // last view attaining the minimum (gipuma.cu:506-510)

@@ -78,7 +78,7 @@ DEVFN void lut_wait_lds(float (&r)[CH], uint32_t after) {
     else if constexpr (CH == 5) asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "v"(after));
     else asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "v"(after));
 }
-template <bool STRICT, int CH>
+template <bool STRICT, int CH, bool BUF = false>
 DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, const unsigned short* tile, int tw, int own, const float* lut,
                           const PixelRef& pr, int x, int y, const float4& n4) {
     constexpr bool ROW = !STRICT;                           // fast mode walks window rows (see pm_core.h, variant bit 7)
@@ -108,6 +108,17 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)((qp + 1) << 2);
     uint32_t qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qa), qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32));
     asm volatile("" : "+s"(qb_lo), "+s"(qb_hi));
+    // BUF (fast mode, from the second sweep of a run on): the gathers as structured buffer loads through a stride-4 resource
+    // descriptor — see pm_core.h, variant bit 17
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s rsrc = {0u, 0u, 0u, 0u};
+    if constexpr (BUF) {
+        rsrc.x = qb_lo;
+        rsrc.y = __builtin_amdgcn_readfirstlane((qb_hi & 0xffffu) | (4u << 16));
+        rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)(qp * (h + 1) - 1));
+        rsrc.w = 0x00020000u;
+        asm volatile("" : "+s"(rsrc));
+    }
     const float cen = tile_value(tile[own]);
     const float fa = (float)(ROW ? x : y), fl = (float)(ROW ? y : x);
     const float uhi = (float)(w - 1), vhi = (float)(h - 1);
@@ -164,8 +175,13 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             }
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-            off_last = (uint32_t)lin << 2;
-            q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off_last);
+            if constexpr (BUF) {
+                off_last = (uint32_t)lin;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
+            } else {
+                off_last = (uint32_t)lin << 2;
+                q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off_last);
+            }
         }
         if constexpr (ROW) lut_wait_lds<CH>(r, off_last);
 #pragma unroll
@@ -183,6 +199,8 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
 #pragma unroll
         for (int jj = 0; jj < CH; jj++) {                   // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;
+            if constexpr (BUF)      // the asm-issued gathers return in order: tap jj has CH - 1 - jj behind it (waits chained, pm_core.h)
+                asm("s_waitcnt vmcnt(%3)" : "+v"(q[jj]), "+v"(sum_src_src) : "v"(q[CH - 1]), "n"(CH - 1 - jj));
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
