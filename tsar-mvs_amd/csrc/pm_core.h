@@ -289,7 +289,9 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
             uint32_t off = 0;
             if (!(V & 64)) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
-            if (V & 131072) {
+            if ((V & 131072) && (V & 262144)) {
+                q[jj] = (uint32_t)lin;                          // experiment (bit 18): the six loads issued back to back after the loop
+            } else if (V & 131072) {
                 asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
             } else if (V & 64) {                                // base already holds the border offset: the byte offset is a plain shift
                 const uint32_t off2 = (uint32_t)lin << 2;
@@ -306,6 +308,11 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
                 q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)(uintptr_t)(((uint64_t)qb_hi << 32) | qb_lo) + off2);
             } else if (V & 4) q[jj] = off * 2654435761u;        // experiment only (TSAR_VARIANT=6): no gather, same arithmetic -> the VALU floor
             else q[jj] = *(global_u32_ptr)((const char __attribute__((address_space(1)))*)vw.quad + off);
+        }
+        if ((V & 131072) && (V & 262144)) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) asm volatile("buffer_load_dword %0, %0, %1, 0 idxen" : "+v"(q[jj]) : "s"(rsrc));
         }
         if (V & 16) __builtin_amdgcn_sched_barrier(0);           // nothing of phase 3 may move above the last gather
         if (V & 32) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
