@@ -46,3 +46,20 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(api.TsarError):
         api.Matcher()
+
+
+def test_chunk_length_of_the_general_window_loop_pads_least():
+    """host logic of the general-window tap loop (pm_sweep_lut.hip lut_chunk_taps): a line of T taps is walked in chunks of 4, 5
+    or 6; the chosen length pads the line least, the longer chunk on a tie.  No GPU needed: the chooser is host code."""
+    import ctypes
+    lib = ctypes.CDLL(api.LIB_PATH)
+    f = getattr(lib, "_Z14lut_chunk_tapsi")
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int]
+    for taps in range(1, 33):
+        ch = f(taps)
+        assert ch in (4, 5, 6)
+        waste = {c: (c - taps % c) % c for c in (4, 5, 6)}
+        assert waste[ch] == min(waste.values()), (taps, ch, waste)
+        assert all(c <= ch for c in (4, 5, 6) if waste[c] == waste[ch]), (taps, ch, waste)
+    assert f(6) == 6 and f(10) == 5 and f(4) == 4 and f(12) == 6 and f(8) == 4      # boxes 11, 19, 7, 23, 15

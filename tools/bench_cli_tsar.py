@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--timing", action="store_true", help="pass --timing to the tool: wall time of each host-side step")
+    ap.add_argument("--workers", type=int, default=1, help="host workers per GPU with --all")
     ap.add_argument("--all", action="store_true", help="refine every view of the scene in ONE process (tsar_gipuma --all --mode=tsar)")
     args = ap.parse_args()
     import torch
@@ -59,7 +60,7 @@ def main():
             tio.write_reliable_mask(apd + "weak.png", good)
         names = [f"{k:08d}.pgm" for k in range(args.views)]
         common = ["-mslp_folder", root, "-images_folder", root + "images/", "--blocksize=11", "--n_best=1", "--mode=tsar", *(["--timing"] if args.timing else [])]
-        cmd = [cli, "--all", "--gpus=1", *common] if args.all else [cli, *names, *common]
+        cmd = [cli, "--all", "--gpus=1", f"--workers={args.workers}", *common] if args.all else [cli, *names, *common]
         n_done = args.views if args.all else 1
         for r in range(args.repeat):
             t0 = time.perf_counter()
