@@ -37,10 +37,10 @@ bool probe_d16_hi_zeroes(tsar_ctx* ctx) {
 template <int NB, int HR>
 static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
-    // structured buffer loads for the gathers (pm_core.h variant bit 17) from the second sweep of a run on: measured per launch
+    // structured buffer loads for the gathers (pm_core.h variant bit 17) from the third sweep of a run on: measured per launch
     // (tools/launch_series.sh) they take 0.6 ms off a converged launch (37.6 -> 37.0) and add 4 ms to the first sweep after the
-    // random initialisation (55.1 -> 59.1), where neighbouring lanes' footprints are unrelated
-    const bool buffer_gather = ctx->buffer_gather && ctx->sweeps_done >= 1;
+    // random initialisation (55.1 -> 59.1), where neighbouring lanes' footprints are unrelated, and 0.3 ms to the second (41.0 -> 41.3)
+    const bool buffer_gather = ctx->buffer_gather && ctx->sweeps_done >= 2;
     // The production configuration (8-bit quad textures, box 11, <= 2 best views) runs the hand-scheduled tap loop of
     // pm_core.h view_cost, in both arithmetic modes: variant 250 in fast mode (row-wise walk), 122 in strict mode, 114 where
     // the D16 probe fails.  In strict mode it is
