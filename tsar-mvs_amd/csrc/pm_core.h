@@ -173,7 +173,31 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
     // (the window then maps into the convex quadrilateral they span), no tap needs the clamp and the wave runs a tap
     // loop without the two v_med3_f32.  Wave-uniform decision, identical results.
     bool need_clamp = true;
-    if (FAST6 && (V & 16)) {
+    if (FAST6 && (V & 16) && (V & 524288)) {
+        // variant bit 19: the same decision without the four reciprocals.  For Z > 0, lo <= X / Z <= hi  <=>  X - lo Z >= 0 and
+        // hi Z - X >= 0, so each corner contributes five margins (four fused multiply-adds and Z itself) and the window is inside
+        // when the smallest of the twenty is positive.  v_min drops NaN operands, so non-finite homographies are caught up front:
+        // sum |H_i| < 1e30 also rules out overflow of the corner terms (|x|, |y| < 2^23).
+        const float mg = (V & 64) ? 1.0f : 0.0f;
+        const float uh = (float)(w - 1) - mg, vh = (float)(h - 1) - mg;
+        float sh = fabsf(H[0]);
+#pragma unroll
+        for (int e = 1; e < 9; e++) sh += fabsf(H[e]);
+        float m = __builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const float yj = (float)(y + (r ? 5 : -5));
+            const float rx = fma_(H[1], yj, H[2]), ry = fma_(H[4], yj, H[5]), rz = fma_(H[7], yj, H[8]);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float xi = (float)(x + (c ? 5 : -5));
+                const float X = fma_(H[0], xi, rx), Y = fma_(H[3], xi, ry), Z = fma_(H[6], xi, rz);
+                const float a = fma_(-mg, Z, X), b = fma_(uh, Z, -X), c2 = fma_(-mg, Z, Y), d = fma_(vh, Z, -Y);
+                m = fminf(fminf(m, fminf(a, b)), fminf(fminf(c2, d), Z));
+            }
+        }
+        need_clamp = !__all(m > 0.0f && sh < 1e30f);
+    } else if (FAST6 && (V & 16)) {
         bool inside = true;
 #pragma unroll
         for (int c = 0; c < 4; c++) {

@@ -77,6 +77,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
                                               : launch_sweep_t<2, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS   // earlier / diagnostic tap-loop variants (make TSAR_EXPERIMENTS=1)
                 case 762: return launch_sweep_t<2, 5, false, true, 762>(ctx, colour, a, b, c, sid, dp, dr);
+                case 655610: return launch_sweep_t<2, 5, false, true, 655610>(ctx, colour, a, b, c, sid, dp, dr);   // buffer loads + division-free corner test
                 case 131290: return launch_sweep_t<2, 5, false, true, 131290>(ctx, colour, a, b, c, sid, dp, dr);   // buffer loads, no wave priority
                 case 393466: return launch_sweep_t<2, 5, false, true, 393466>(ctx, colour, a, b, c, sid, dp, dr);   // 250 + buffer loads, issued back to back
                 case 131322: return launch_sweep_t<2, 5, false, true, 131322>(ctx, colour, a, b, c, sid, dp, dr);   // 250 + buffer loads in every launch
