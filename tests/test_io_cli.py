@@ -326,3 +326,19 @@ def test_cli_display_outputs(tmp_path):
     assert np.allclose(rec["p"].transpose(1, 0, 2), world, atol=1e-4)
     assert np.array_equal(rec["n"].transpose(1, 0, 2), normal)
     assert np.array_equal(rec["c"][..., 0].T, sc.images[0].numpy().astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_cli_more_gpus_requested_than_present_fails_cleanly(tmp_path):
+    """--all --gpus=N with N beyond the devices of the box: the views dealt to the missing devices fail with a message, the tool
+    returns non-zero (no crash, no hang), and the views dealt to device 0 are still written"""
+    import torch
+    n_dev = torch.cuda.device_count()
+    sc = synth.make_scene(128, 96, 3, seed=5)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    out = subprocess.run([CLI, "--all", f"--gpus={n_dev + 1}", "-mslp_folder", root, "-images_folder", root + "images/", "--iterations=1", "--blocksize=11", "--n_best=1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "tsar_create" in out.stderr
+    assert os.path.exists(root + "APD/00000000/TSAR_disp.dmb")
