@@ -686,8 +686,9 @@ def test_line_closing_separates_regions_that_leak_through_a_gap():
 
 
 # ---- row N3: fusion ----------------------------------------------------------------------------------------
-def test_fusion_bit_exact():
-    sc = synth.make_scene(160, 120, 4, seed=8, all_gt=True)
+@pytest.mark.parametrize("w,h,n_src", [(160, 120, 4), (2016, 1344, 5)])
+def test_fusion_bit_exact(w, h, n_src):
+    sc = synth.make_scene(w, h, n_src, seed=8, all_gt=True)
     n = len(sc.images)
     depths = [d.numpy() for d, _ in sc.meta["gt_all"]]
     # perturb: a noisy band and some holes so that the consistency tests actually reject things
