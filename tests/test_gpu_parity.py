@@ -632,6 +632,24 @@ def test_slic_labels_exact(S, iters, conn, space):
     m.close()
 
 
+def test_slic_labels_exact_at_the_quarter_resolution_of_an_eth3d_view():
+    """BASELINE configs[3]: gSLICr runs on the 1512 x 1008 quarter-resolution image, superpixel size 20, 5 iterations, CIELAB
+    (main.cpp:1506-1517)"""
+    rng = np.random.default_rng(20)
+    h, w = 1008, 1512
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0] = (127 + 100 * np.sin(xx / 37.0) * np.cos(yy / 53.0)).astype(np.uint8)
+    img[..., 1] = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
+    img[..., 2] = (rng.integers(0, 30, size=(h, w)) + 100 * ((xx // 90 + yy // 70) % 2)).astype(np.uint8)
+    img[..., 3] = 255
+    m = api.Matcher()
+    got = m.slic(img, api.SlicSettings(20, 5, 5.0, 1, 0))
+    ref = ol.slic(img, 20, 5, 5.0, 1, 0)
+    assert np.array_equal(got, ref)
+    m.close()
+
+
 # ---- row N2: weak-texture region detection -------------------------------------------------------------
 def _weak_scene(w=1216, h=832):
     """a scene with large constant-albedo patches (the 'textureless' variant of the synthetic scene)"""
