@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--workers", type=int, nargs="+", default=[1, 2])
+    ap.add_argument("--timing", action="store_true", help="pass --timing to the tool and print the last view's steps")
     ap.add_argument("--fuse", action="store_true", help="also fuse the views in the same process (--all --fuse): matched maps -> APD/APD_TSAR.ply")
     ap.add_argument("--fusion-cli", action="store_true", dest="fusion_cli", help="then run the separate tsar_fusion tool on the written .dmb files")
     args = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
         for wk in args.workers:
             t0 = time.perf_counter()
             out = subprocess.run([cli, "--all", "--gpus=1", f"--workers={wk}", "-mslp_folder", root, "-images_folder", root + "images/",
-                                  f"--iterations={args.iters}", "--blocksize=11", "--n_best=1", *(["--fuse"] if args.fuse else [])], capture_output=True, text=True)
+                                  f"--iterations={args.iters}", "--blocksize=11", "--n_best=1", *(["--fuse"] if args.fuse else []), *(["--timing"] if args.timing else [])], capture_output=True, text=True)
             dt = time.perf_counter() - t0
             ok = out.returncode == 0 and all(os.path.exists(root + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(args.views))
             mp = args.width * args.height * args.views / dt / 1e6
@@ -49,6 +50,8 @@ def main():
                 print(out.stdout[-2000:], out.stderr[-2000:])
             else:
                 print("   " + " | ".join(l for l in out.stdout.splitlines() if l.startswith("view"))[:600])
+                if args.timing:
+                    print("   " + " || ".join([l for l in out.stdout.splitlines() if " steps (ms)" in l or "kernels (launches" in l][-2:])[:1500])
                 for l in out.stdout.splitlines():
                     if l.startswith("fused"):
                         print("   " + l)

@@ -332,14 +332,16 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     ctx->have_views = false;
     ctx->have_state = false;
     ctx->have_out = false;
-    free_views(ctx);
+    // The image and quad-texture buffers of the previous views are kept when the size is the same (a worker matching view after
+    // view of a scene): 2 x n_views hipMalloc + hipFree of ~100 MB each cost 55 ms per call at ETH3D size, more than the copies.
+    // Buffers beyond n_views stay in the pool; a change of size releases everything.
     const size_t np = (size_t)w * h;
-    if (w != ctx->w || h != ctx->h) free_planes(ctx);
+    if (w != ctx->w || h != ctx->h) { free_views(ctx); free_planes(ctx); }
     ctx->w = w; ctx->h = h; ctx->n_views = n_views;
     DevScene& sc = ctx->hscene;
     sc.w = w; sc.h = h; sc.quad_pitch = w + 2;
-    ctx->img.assign(n_views, nullptr);
-    ctx->quad.assign(n_views, nullptr);
+    if ((int)ctx->img.size() < n_views) ctx->img.resize(n_views, nullptr);
+    if ((int)ctx->quad.size() < n_views) ctx->quad.resize(n_views, nullptr);
     struct DevInt {   // freed on every exit path
         int* p = nullptr;
         ~DevInt() { if (p) hipFree(p); }
@@ -348,8 +350,8 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     int* const dflag = dflag_owner.p;
     hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream);
     for (int v = 0; v < n_views; v++) {
-        TRY(dev_alloc(ctx, &ctx->img[v], np));
-        TRY(dev_alloc(ctx, &ctx->quad[v], (size_t)(w + 2) * (h + 2)));
+        if (!ctx->img[v]) TRY(dev_alloc(ctx, &ctx->img[v], np));
+        if (!ctx->quad[v]) TRY(dev_alloc(ctx, &ctx->quad[v], (size_t)(w + 2) * (h + 2)));
         TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->img[v], gray[v], np * sizeof(float), in_kind(mem), ctx->stream));
         TRY(launch_build_quad(ctx, ctx->img[v], ctx->quad[v], w, h, dflag));
     }
@@ -359,7 +361,7 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     sc.use_quad = hflag ? 0 : 1;
     for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; }
     if (!sc.use_quad)
-        for (auto& q : ctx->quad) dev_free(q);
+        for (auto& q : ctx->quad) dev_free(q);              // (float imagery: the textures are not used; re-allocated if a later call needs them)
     derive_cameras(ctx, cams);
     fill_scene_params(ctx);
     if (!lut_path_applies(ctx)) {
