@@ -78,12 +78,20 @@ struct TmpIn {   // device view of a caller buffer (copies host buffers in)
     const T* d = nullptr;
     T* owned = nullptr;
     int rc = TSAR_OK;
-    TmpIn(tsar_ctx* c, const T* src, size_t n, int mem) : ctx(c) {
+    // scratch: take the staging buffer from the context's arena (tsar_dev.h ScratchScope) instead of a hipMalloc per call
+    TmpIn(tsar_ctx* c, const T* src, size_t n, int mem, ScratchScope* scratch = nullptr) : ctx(c) {
         if (!src) return;
         if (mem == TSAR_MEM_DEVICE) { d = src; return; }
-        rc = dev_alloc(ctx, &owned, n);
-        if (rc == TSAR_OK && hipMemcpyAsync(owned, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "H2D failed");
-        d = owned;
+        T* staging = nullptr;
+        if (scratch) {
+            staging = (T*)scratch->alloc(n * sizeof(T));
+            if (!staging) rc = fail(ctx, TSAR_ERR_NOMEM, "hipMalloc failed");
+        } else {
+            rc = dev_alloc(ctx, &owned, n);
+            staging = owned;
+        }
+        if (rc == TSAR_OK && hipMemcpyAsync(staging, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "H2D failed");
+        d = staging;
     }
     ~TmpIn() {
         if (owned) { hipStreamSynchronize(ctx->stream); hipFree(owned); }
@@ -570,7 +578,8 @@ extern "C" int tsar_load_planes(tsar_ctx* ctx, const float* depth, const float* 
     NEED_VIEWS(ctx);
     if (!depth || !normal_world) return fail(ctx, TSAR_ERR_INVALID, "depth/normal_world is NULL");
     const size_t np = (size_t)ctx->w * ctx->h;
-    TmpIn<float> d(ctx, depth, np, mem), n(ctx, normal_world, 3 * np, mem);
+    ScratchScope scratch(ctx);             // host maps are staged through the context's scratch arena (released after the sync below)
+    TmpIn<float> d(ctx, depth, np, mem, &scratch), n(ctx, normal_world, 3 * np, mem, &scratch);
     TRY(d.rc); TRY(n.rc);
     TRY(launch_get_disp(ctx, d.d, n.d));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -617,15 +626,16 @@ extern "C" int tsar_get_result(tsar_ctx* ctx, float* depth, float* normal_world,
         if (mem == TSAR_MEM_DEVICE) {
             TRY(launch_split_out4(ctx, depth, normal_world));
         } else {
+            ScratchScope scratch(ctx);     // the split maps are staged in the context's scratch arena
             float *dd = nullptr, *dn = nullptr;
             int rc = TSAR_OK;
-            if (depth) rc = dev_alloc(ctx, &dd, np);
-            if (rc == TSAR_OK && normal_world) rc = dev_alloc(ctx, &dn, 3 * np);
+            if (depth && !(dd = (float*)scratch.alloc(np * 4))) rc = fail(ctx, TSAR_ERR_NOMEM, "hipMalloc failed");
+            if (rc == TSAR_OK && normal_world && !(dn = (float*)scratch.alloc(np * 12))) rc = fail(ctx, TSAR_ERR_NOMEM, "hipMalloc failed");
             if (rc == TSAR_OK) rc = launch_split_out4(ctx, dd, dn);
             if (rc == TSAR_OK && depth && hipMemcpyAsync(depth, dd, np * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "D2H failed");
             if (rc == TSAR_OK && normal_world && hipMemcpyAsync(normal_world, dn, np * 12, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "D2H failed");
             hipStreamSynchronize(ctx->stream);
-            dev_free(dd); dev_free(dn);
+            scratch.release();
             TRY(rc);
         }
     }
