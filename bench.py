@@ -124,9 +124,18 @@ def host_boundary(args, sc):
     bufs = {"pinned": {k: api.pinned_empty(v, np.float32) for k, v in shapes.items()},      # allocated (and touched) once, outside
             "pageable": {k: np.zeros(v, np.float32) for k, v in shapes.items()}}            # the timed step, like a host loop over views
     out = {}
+    # one context for both legs, like a host loop over the views of a scene: its device buffers (images, quad textures, planes, the
+    # staging arena of tsar_get_result) exist after the first view, so two untimed rounds come first.  (A context created after
+    # another one was destroyed pays ~5 ms per hipMalloc for memory the runtime had returned: an artefact of creating contexts in
+    # a loop, not part of a view's cost.)
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=args.box, box_vsize=args.box, n_best=args.n_best, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=2024))
+    for _ in range(2):
+        m.set_views(pinned, sc.K, sc.R, sc.t)
+        m.pm_init()
+        m.compute_disp()
+        m.get_result(out=bufs["pinned"])
     for leg, imgs in (("pinned", pinned), ("pageable", pageable)):
-        m = api.Matcher()
-        m.set_params(api.default_params(box_hsize=args.box, box_vsize=args.box, n_best=args.n_best, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=2024))
         t0 = time.perf_counter()
         m.set_views(imgs, sc.K, sc.R, sc.t)
         t1 = time.perf_counter()
@@ -136,9 +145,9 @@ def host_boundary(args, sc):
         t2 = time.perf_counter()
         m.get_result(out=bufs[leg])
         t3 = time.perf_counter()
-        m.close()
         out[leg] = {"value": w * h / (t3 - t0) / 1e6, "unit": "Mpix/s", "set_views_h2d_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3,
                     "get_result_d2h_ms": (t3 - t2) * 1e3}
+    m.close()
     return {"value": out["pinned"]["value"], "unit": "Mpix/s", "pinned": out["pinned"], "pageable": out["pageable"],
             "note": "host buffers in (H2D + quad build), host buffers out (D2H); one view; value = page-locked caller buffers (tsar_host_alloc)"}
 

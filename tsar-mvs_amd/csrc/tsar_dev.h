@@ -88,6 +88,8 @@ struct KernelTimer {
 struct ScratchArena {
     char* base = nullptr;
     size_t cap = 0;
+    size_t wanted = 0;      // the largest call that did not fit so far: the arena is (re)built the second time one overflows, so a
+                            // context that makes each call once (one view per process) never pays for an arena it would not reuse
 };
 
 struct tsar_ctx {
@@ -126,7 +128,8 @@ struct tsar_ctx {
 };
 
 // One operator call's view of the arena: alloc() hands out 256-byte-aligned pieces; what does not fit is a plain hipMalloc for
-// this call, and the arena is re-sized to the call's total on release, so the next call of that size allocates nothing.
+// this call; the second time a call overflows, the arena is re-sized to the largest total seen, and calls of that size allocate
+// nothing from then on.
 struct ScratchScope {
     tsar_ctx* ctx;
     size_t used = 0, need = 0;
@@ -145,11 +148,15 @@ struct ScratchScope {
         for (void* p : extra) hipFree(p);
         extra.clear();
         if (need > ctx->scratch.cap) {
-            if (ctx->scratch.base) hipFree(ctx->scratch.base);
-            ctx->scratch.base = nullptr;
-            ctx->scratch.cap = 0;
-            void* p = nullptr;
-            if (hipMalloc(&p, need) == hipSuccess) { ctx->scratch.base = (char*)p; ctx->scratch.cap = need; }
+            const bool again = ctx->scratch.wanted > ctx->scratch.cap;          // an earlier call overflowed this arena too
+            if (need > ctx->scratch.wanted) ctx->scratch.wanted = need;
+            if (again) {
+                if (ctx->scratch.base) hipFree(ctx->scratch.base);
+                ctx->scratch.base = nullptr;
+                ctx->scratch.cap = 0;
+                void* p = nullptr;
+                if (hipMalloc(&p, ctx->scratch.wanted) == hipSuccess) { ctx->scratch.base = (char*)p; ctx->scratch.cap = ctx->scratch.wanted; }
+            }
         }
         used = need = 0;
     }
