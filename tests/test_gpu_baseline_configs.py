@@ -381,3 +381,19 @@ def test_live_path_full_size_bit_exact():
     rep = json.loads(out.stdout)
     assert rep["all_bit_identical"] is True and len(rep["steps"]) == 5
     assert rep["median_relative_depth_error_there"]["after"] < 1e-3 < rep["median_relative_depth_error_there"]["before"]
+
+
+def test_bench_workload_full_size_first_steps_bit_exact():
+    """BASELINE configs[1] at its full size (6048x4032, 1 + 10 views), strict mode against the oracle: the random initialisation
+    (one scored hypothesis per pixel and view: the whole cost function on 24.4 M pixels) and the exported maps, bit for bit
+    (tools/full_size_oracle_check.py --iters 0: ~11 s of oracle time).  With iterations the same script needs ~2 minutes of 16
+    host cores each and is kept as a recorded run (profiles/r02/full_size_oracle_check.json: five iterations, all bit-identical)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "full_size_oracle_check.py"), "--iters", "0"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rep = json.loads(out.stdout)
+    assert rep["all_bit_identical"] is True and rep["steps"][0]["after"] == "pm_init" and rep["steps"][0]["pixels"] == 6048 * 4032
