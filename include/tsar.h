@@ -277,6 +277,19 @@ int tsar_reset_kernel_timing(tsar_ctx* ctx);
 /* fills up to `cap` records, returns the number of distinct kernels in *n_out */
 int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, int cap, int* n_out);
 
+/* ---- self-tests ---------------------------------------------------------------------------- */
+/* TSAR_FLAG_STRICT_DIV's perspective divide u = X / Z, v = Y / Z (getCorrespondingPoint_cu gipuma.cu:161-171, vecdiv4) is computed
+ * with one v_rcp_f32 + Newton step and one residual correction per quotient instead of the compiler's IEEE division sequence, behind
+ * an operand guard that falls back to the latter.  These run that code path on caller-supplied or device-generated operands so a
+ * test can compare it with IEEE division (the host's `/`, or the device's) bit for bit.
+ *   tsar_selftest_divide: host arrays in / out; ieee != 0 returns the device's IEEE quotients instead.
+ *   tsar_selftest_divide_random: 2^log2_triples (X, Y, Z) triples generated on the device (mode 0: like the tap loop's operands;
+ *   1: any mantissa / sign, exponents across the guard range; 2: any bit pattern); guarded = 0 runs the form without the guard (the
+ *   clamp-free tap loops; modes 0 and 1).  Returns the number of quotients that differ from `/` and of triples outside the guard. */
+int tsar_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u_out, float* v_out, int ieee);
+int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint64_t seed, int mode, int guarded, uint64_t* mismatches_out,
+                                uint64_t* outside_guard_out);
+
 #ifdef __cplusplus
 }
 #endif

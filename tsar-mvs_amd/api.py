@@ -66,6 +66,7 @@ ABI_SYMBOLS = [
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse",
     "tsar_host_alloc", "tsar_host_free", "tsar_device_alloc", "tsar_device_free", "tsar_device_write", "tsar_peer_copy", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
+    "tsar_selftest_divide", "tsar_selftest_divide_random",
 ]
 
 _lib = None
@@ -136,6 +137,8 @@ def load_library(path: str = LIB_PATH):
     L.tsar_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.tsar_reset_kernel_timing.argtypes = [C.c_void_p]
     L.tsar_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming), C.c_int, C.POINTER(C.c_int)]
+    L.tsar_selftest_divide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    L.tsar_selftest_divide_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -327,6 +330,21 @@ class Matcher:
 
     def lrdiff(self):
         self._chk(self.L.tsar_lrdiff(self._ctx))
+
+    # ---- self-tests ----
+    def selftest_divide(self, X, Y, Z, ieee: bool = False):
+        """(u, v) = (X / Z, Y / Z) as strict mode's tap loops compute them (ieee: as the device's IEEE division does)."""
+        X, Y, Z = (np.ascontiguousarray(a, dtype=np.float32) for a in (X, Y, Z))
+        assert X.shape == Y.shape == Z.shape
+        u, v = np.empty_like(X), np.empty_like(X)
+        self._chk(self.L.tsar_selftest_divide(self._ctx, _ptr(X)[0], _ptr(Y)[0], _ptr(Z)[0], X.size, _ptr(u)[0], _ptr(v)[0], int(ieee)))
+        return u, v
+
+    def selftest_divide_random(self, log2_triples: int, seed: int, mode: int, guarded: bool = True):
+        """(quotients differing from IEEE division, triples outside the operand guard) over 2^log2_triples device-generated triples."""
+        bad, out = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.L.tsar_selftest_divide_random(self._ctx, log2_triples, seed, mode, int(guarded), C.byref(bad), C.byref(out)))
+        return bad.value, out.value
 
     def getview(self):
         self._chk(self.L.tsar_getview(self._ctx))

@@ -199,6 +199,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
         need_clamp = !__all(m > 0.0f && sh < 1e30f);
     } else if (FAST6 && (V & 16)) {
         bool inside = true;
+        float zmin = __builtin_inff(), zmax = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const float xi = (float)(x + ((c & 1) ? 5 : -5)), yj = (float)(y + ((c & 2) ? 5 : -5));
@@ -209,6 +210,22 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             // floor(u) = -1, so the corners keep one pixel of margin (rounding moves a tap by ~1e-4 pixel at most)
             const float mg = (V & 64) ? 1.0f : 0.0f;
             inside = inside && Z > 0.0f && u >= mg && u <= (float)(w - 1) - mg && v >= mg && v <= (float)(h - 1) - mg;
+            if (STRICT) { zmin = fminf(zmin, Z); zmax = fmaxf(zmax, Z); }
+        }
+        if (STRICT && (V & 64)) {
+            // The clamp-free loop of strict mode also drops the per-tap operand guard of persp_divide_exact, so "inside" must imply
+            // that X, Y, Z of EVERY tap lie in [2^-20, 2^38].  With cm >= |x|, |y| of any tap: Z is affine in the tap position, so at
+            // every tap it lies between the corner values up to the rounding of its three-term evaluation, dZ <= 3 * 2^-24 * sz with
+            // sz = (|H6| + |H7|) cm + |H8|.  sz cm <= 2^19 zmin bounds dZ / Z by 3 * 2^-5 / cm <= 1.2 % (cm >= 8), so Z stays in
+            // [2^-19, 2^18] for zmin >= 2^-18, zmax <= 2^17.  u = X / Z of a tap lies in the hull of the corners' true u (Z > 0: the
+            // map is projective), which are >= 1 - 0.15: computed u >= 1, and a computed corner is off by u dZ / Z <= cm * 3 * 2^-24
+            // * 2^19 / cm = 0.094 plus dX / Z <= 3 * 2^-24 * sx / zmin <= 0.047 for sx = (|H0| + |H1|) cm + |H2| <= 2^18 zmin.  Hence
+            // X >= 0.8 zmin >= 2^-20 and |X| <= sx <= 2^35; the same for Y.
+            const float cm = (float)(max(w, h) + 32);
+            const float sz = fma_(fabsf(H[6]) + fabsf(H[7]), cm, fabsf(H[8]));
+            const float sx = fma_(fabsf(H[0]) + fabsf(H[1]), cm, fabsf(H[2]));
+            const float sy = fma_(fabsf(H[3]) + fabsf(H[4]), cm, fabsf(H[5]));
+            inside = inside && zmin >= 3.814697265625e-06f && zmax <= 131072.0f && sz * cm <= 524288.0f * zmin && fmaxf(sx, sy) <= 262144.0f * zmin;
         }
         need_clamp = !__all(inside);
     }
@@ -282,18 +299,26 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             // bit for bit: for u in [-1, 0) both texels of the pair are T(0) (edge replication), so the blend returns T(0) whatever
             // the fraction — exactly what u = 0 returns (fraction 0); likewise beyond w - 1, and per axis.
             const float ulo = (V & 64) ? 0.0f : -1.0f, uhi = (V & 64) ? (float)(w - 1) : (float)w, vhi = (V & 64) ? (float)(h - 1) : (float)h;
-            if (STRICT) {                                       // the oracle's operations: IEEE divides, min/max clamp, floor / subtract
-                u = X / Z;
-                v = Y / Z;
+            if (STRICT) {                                       // the oracle's values: correctly rounded quotients, min/max clamp, floor / subtract
+                persp_divide_exact<CLAMP || !(V & 64) || !(V & 16)>(X, Y, Z, u, v);   // clamp-free loop: guard shown by the corner test
                 if (CLAMP) {
                     u = fminf(fmaxf(u, ulo), uhi);
                     v = fminf(fmaxf(v, ulo), vhi);
                 }
-                const float fu = floorf(u), fv = floorf(v);
-                ax[jj] = u - fu;
-                ay[jj] = v - fv;
-                iu = (int)fu;
-                iv = (int)fv;
+                if (V & 64) {
+                    // u, v >= 0 here (clamped to [0, w - 1], or inside the image by the corner test): v_fract_f32 = u - floor(u)
+                    // exactly (the difference is representable), v_cvt_flr_i32_f32 = (int)floor(u)
+                    ax[jj] = __builtin_amdgcn_fractf(u);
+                    ay[jj] = __builtin_amdgcn_fractf(v);
+                    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+                    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
+                } else {
+                    const float fu = floorf(u), fv = floorf(v);
+                    ax[jj] = u - fu;
+                    ay[jj] = v - fv;
+                    iu = (int)fu;
+                    iv = (int)fv;
+                }
             } else {
                 const float rz = __builtin_amdgcn_rcpf(Z);
                 u = X * rz;
@@ -499,8 +524,7 @@ DEVFN float view_cost(const DevScene* __restrict__ sc, const DevView& vw, const 
             const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
             float u, v;
             if (STRICT) {
-                u = X / Z;
-                v = Y / Z;
+                persp_divide_exact<true>(X, Y, Z, u, v);
             } else {
                 const float rz = __builtin_amdgcn_rcpf(Z);
                 u = X * rz;

@@ -93,6 +93,7 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     // are sampled where they fall, beyond the window's right edge: the corners include them.
     const int xr = ROW ? 2 * (sc->lut_pad_taps - 1) - hr : hr;
     bool inside = true;
+    float zmin = __builtin_inff(), zmax = 0.0f;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float xi = (float)(x + ((c & 1) ? xr : -hr)), yj = (float)(y + ((c & 2) ? vr : -vr));
@@ -100,6 +101,14 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
         const float rz = __builtin_amdgcn_rcpf(Z);
         const float u = X * rz, v = Y * rz;
         inside = inside && Z > 0.0f && u >= 1.0f && u <= (float)(w - 2) && v >= 1.0f && v <= (float)(h - 2);
+        if (STRICT) { zmin = fminf(zmin, Z); zmax = fmaxf(zmax, Z); }
+    }
+    if (STRICT) {       // the clamp-free strict loop runs persp_divide_exact without its per-tap guard: see view_cost (pm_core.h) for the bounds
+        const float cm = (float)(max(w, h) + 32);
+        const float sz = fma_(fabsf(H[6]) + fabsf(H[7]), cm, fabsf(H[8]));
+        const float sx = fma_(fabsf(H[0]) + fabsf(H[1]), cm, fabsf(H[2]));
+        const float sy = fma_(fabsf(H[3]) + fabsf(H[4]), cm, fabsf(H[5]));
+        inside = inside && zmin >= 3.814697265625e-06f && zmax <= 131072.0f && sz * cm <= 524288.0f * zmin && fmaxf(sx, sy) <= 262144.0f * zmin;
     }
     const bool need_clamp = !__all(inside);
     // quad-texture base with the border offset folded in, pinned in an SGPR pair for the whole view (pm_core.h, variant bit 6):
@@ -149,17 +158,16 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             float u, v;
             int iu, iv;
             if (STRICT) {                                   // the oracle's operations: IEEE divides, min/max clamp, floor / subtract
-                u = X / Z;
-                v = Y / Z;
+                persp_divide_exact<CLAMP>(X, Y, Z, u, v);   // = X / Z, Y / Z bit for bit (tsar_device_math.h); clamp-free: guard shown by the corner test
                 if (CLAMP) {
                     u = fminf(fmaxf(u, 0.0f), uhi);
                     v = fminf(fmaxf(v, 0.0f), vhi);
                 }
-                const float fu = floorf(u), fv = floorf(v);
-                ax[jj] = u - fu;
-                ay[jj] = v - fv;
-                iu = (int)fu;
-                iv = (int)fv;
+                // u, v >= 0 (clamped, or inside the image by the corner test): fract = u - floor(u) exactly
+                ax[jj] = __builtin_amdgcn_fractf(u);
+                ay[jj] = __builtin_amdgcn_fractf(v);
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
             } else {
                 const float rz = __builtin_amdgcn_rcpf(Z);
                 u = X * rz;

@@ -52,7 +52,8 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
         bool small = tiles256 < SWEEP_SMALL_IMAGE_TILES;
         if (const char* e = getenv("TSAR_BLOCK")) small = atoi(e) == 128;
         if (small && (ctx->variant == 250 || ctx->variant == 122)) {
-            if (strict) return launch_sweep_t<2, 5, true, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
+            if (strict) return buffer_gather ? launch_sweep_t<2, 5, true, true, 131194, 128>(ctx, colour, a, b, c, sid, dp, dr)
+                                             : launch_sweep_t<2, 5, true, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
             if (ctx->variant == 250 && buffer_gather) return launch_sweep_t<2, 5, false, true, 131322, 128>(ctx, colour, a, b, c, sid, dp, dr);
             return ctx->variant == 250 ? launch_sweep_t<2, 5, false, true, 250, 128>(ctx, colour, a, b, c, sid, dp, dr)
                                        : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
@@ -60,7 +61,8 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
         if (strict) {
             switch (ctx->variant) {
                 case 250:       // the row-wise walk is a fast-mode liberty: strict runs the same loop in the oracle's column order
-                case 122: return launch_sweep_t<2, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+                case 122: return buffer_gather ? launch_sweep_t<2, 5, true, true, 131194>(ctx, colour, a, b, c, sid, dp, dr)    // 122 + bit 17
+                                                : launch_sweep_t<2, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
                 case 114: return launch_sweep_t<2, 5, true, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
 #ifdef TSAR_EXPERIMENTS
                 case 58: return launch_sweep_t<2, 5, true, true, 58>(ctx, colour, a, b, c, sid, dp, dr);
@@ -99,7 +101,8 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     }
     // box 11 with three or four best views: the same tap loop, four-register selection (256-thread workgroups only)
     if (quad && NB == 4 && HR == 5 && !(ctx->hscene.flags & TSAR_FLAG_TEX_FILTER_8BIT) && (ctx->variant == 250 || ctx->variant == 122)) {
-        if (strict) return launch_sweep_t<4, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+        if (strict) return buffer_gather ? launch_sweep_t<4, 5, true, true, 131194>(ctx, colour, a, b, c, sid, dp, dr)
+                                         : launch_sweep_t<4, 5, true, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
         if (ctx->variant == 250 && buffer_gather) return launch_sweep_t<4, 5, false, true, 131322>(ctx, colour, a, b, c, sid, dp, dr);
         return ctx->variant == 250 ? launch_sweep_t<4, 5, false, true, 250>(ctx, colour, a, b, c, sid, dp, dr)
                                    : launch_sweep_t<4, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);

@@ -1,0 +1,76 @@
+// selftest_kernels.hip — device self-tests behind the C ABI (include/tsar.h "self-tests"): the strict mode's perspective divide
+// (tsar_device_math.h persp_divide_exact) against the IEEE division the oracle uses (getCorrespondingPoint_cu gipuma.cu:161-171).
+// tools/div_exact.hip is the exhaustive proof over all mantissa pairs; these entry points let the GPU test suite re-check the
+// shipped code path — operands drawn like the tap loop's, across the whole guard range, and across all of fp32 — in milliseconds.
+#include "tsar_device_math.h"
+
+#define ST_BLOCK 256
+
+__global__ __launch_bounds__(ST_BLOCK) void divide_arrays_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ Z,
+                                                                 size_t n, float* __restrict__ u, float* __restrict__ v, int ieee) {
+    const size_t i = (size_t)blockIdx.x * ST_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float a, b;
+    if (ieee) { a = X[i] / Z[i]; b = Y[i] / Z[i]; }
+    else persp_divide_exact<true>(X[i], Y[i], Z[i], a, b);
+    u[i] = a;
+    v[i] = b;
+}
+
+DEVFN bool same_quotient(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+
+// mode 0: operands like the tap loop's — Z in [2^-4, 2^4), u in [-64, 8256), v likewise, X = u Z, Y = v Z
+// mode 1: random mantissas and signs, exponents uniform over the guard range [2^-20, 2^38)
+// mode 2: any bit pattern (denormals, zeros, infinities, NaN, huge and tiny): the guard must catch what the short form cannot do
+// guarded = 0 (modes 0 and 1 only): the unguarded form the clamp-free loops run
+__global__ __launch_bounds__(ST_BLOCK) void divide_random_kernel(uint32_t per_thread, uint32_t seed_lo, uint32_t seed_hi, int mode, int guarded,
+                                                                 unsigned long long* out) {
+    const uint32_t tid = blockIdx.x * ST_BLOCK + threadIdx.x;
+    uint32_t bad = 0, fell_back = 0;
+    for (uint32_t k = 0; k < per_thread; k++) {
+        const Rand4 rn = philox_uniform4(tid, k, 0x5eedu, seed_lo, seed_hi);
+        const Rand4 rm = philox_uniform4(tid, k, 0x5eeeu, seed_lo, seed_hi);
+        float X, Y, Z;
+        if (mode == 0) {
+            Z = __builtin_ldexpf(1.0f + rn.u[0], (int)(rn.u[1] * 8.0f) - 4);
+            X = between(rn.u[2], -64.0f, 8256.0f) * Z;
+            Y = between(rn.u[3], -64.0f, 8256.0f) * Z;
+        } else {
+            // 24 random bits per uniform: mantissa from one, exponent / sign from another
+            const uint32_t b0 = (uint32_t)(rn.u[0] * 16777216.0f) - 1u, b1 = (uint32_t)(rn.u[1] * 16777216.0f) - 1u, b2 = (uint32_t)(rn.u[2] * 16777216.0f) - 1u;
+            const uint32_t e0 = (uint32_t)(rm.u[0] * 16777216.0f) - 1u, e1 = (uint32_t)(rm.u[1] * 16777216.0f) - 1u, e2 = (uint32_t)(rm.u[2] * 16777216.0f) - 1u;
+            auto make = [&](uint32_t m, uint32_t e) {
+                const uint32_t ex = mode == 1 ? 107u + (e >> 1) % 58u : (e >> 1) & 0xffu;     // 2^-20 .. 2^37, or anything
+                return __uint_as_float(((e & 1u) << 31) | (ex << 23) | (m & 0x7fffffu));
+            };
+            X = make(b0, e0); Y = make(b1, e1); Z = make(b2, e2);
+        }
+        float a, b;
+        if (guarded) persp_divide_exact<true>(X, Y, Z, a, b);
+        else div_pair_rcp_exact(X, Y, Z, a, b);
+        bad += !same_quotient(a, X / Z);
+        bad += !same_quotient(b, Y / Z);
+        fell_back += !div_guard_ok(X, Y, Z);
+    }
+    for (int o = 32; o; o >>= 1) { bad += __shfl_down(bad, o); fell_back += __shfl_down(fell_back, o); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], (unsigned long long)bad);
+        atomicAdd(&out[1], (unsigned long long)fell_back);
+    }
+}
+
+int launch_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u, float* v, int ieee) {
+    hipLaunchKernelGGL(divide_arrays_kernel, dim3((unsigned)((n + ST_BLOCK - 1) / ST_BLOCK)), dim3(ST_BLOCK), 0, ctx->stream, X, Y, Z, n, u, v, ieee);
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
+int launch_selftest_divide_random(tsar_ctx* ctx, int log2_pairs, uint64_t seed, int mode, int guarded, unsigned long long* dcounts) {
+    // 2^log2_pairs triples (two quotients each) over 2^20 threads at most
+    const int lt = log2_pairs < 20 ? log2_pairs : 20;
+    const uint32_t threads = 1u << lt, per_thread = 1u << (log2_pairs - lt);
+    hipLaunchKernelGGL(divide_random_kernel, dim3((threads + ST_BLOCK - 1) / ST_BLOCK), dim3(threads < ST_BLOCK ? threads : ST_BLOCK), 0, ctx->stream, per_thread,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), mode, guarded, dcounts);
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}

@@ -809,3 +809,45 @@ extern "C" int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, in
     }
     return TSAR_OK;
 }
+
+// ---- self-tests (selftest_kernels.hip) ---------------------------------------------------------------------------------------
+extern "C" int tsar_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u_out, float* v_out, int ieee) {
+    CHECK_CTX(ctx);
+    if (!X || !Y || !Z || !u_out || !v_out || n == 0 || n > ((size_t)1 << 28)) return fail(ctx, TSAR_ERR_INVALID, "NULL argument or n out of range (1..2^28)");
+    ScratchScope scratch(ctx);
+    float* d[5];
+    for (auto& p : d)
+        if (!(p = (float*)scratch.alloc(n * sizeof(float)))) { scratch.release(); return fail(ctx, TSAR_ERR_NOMEM, "device allocation failed"); }
+    const float* src[3] = {X, Y, Z};
+    int rc = TSAR_OK;
+    for (int k = 0; k < 3 && rc == TSAR_OK; k++)
+        if (hipMemcpyAsync(d[k], src[k], n * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemcpyAsync failed");
+    if (rc == TSAR_OK) rc = launch_selftest_divide(ctx, d[0], d[1], d[2], n, d[3], d[4], ieee);
+    if (rc == TSAR_OK && (hipMemcpyAsync(u_out, d[3], n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                          hipMemcpyAsync(v_out, d[4], n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess))
+        rc = fail(ctx, TSAR_ERR_HIP, "hipMemcpyAsync failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
+    scratch.release();
+    return rc;
+}
+extern "C" int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint64_t seed, int mode, int guarded, uint64_t* mismatches_out,
+                                           uint64_t* outside_guard_out) {
+    CHECK_CTX(ctx);
+    if (log2_triples < 6 || log2_triples > 36 || mode < 0 || mode > 2 || !mismatches_out) return fail(ctx, TSAR_ERR_INVALID, "log2_triples in 6..36, mode in 0..2");
+    if (!guarded && mode == 2) return fail(ctx, TSAR_ERR_INVALID, "the unguarded form is only defined inside the guard (modes 0, 1)");
+    ScratchScope scratch(ctx);
+    unsigned long long* dc = (unsigned long long*)scratch.alloc(2 * sizeof(unsigned long long));
+    if (!dc) { scratch.release(); return fail(ctx, TSAR_ERR_NOMEM, "device allocation failed"); }
+    unsigned long long hc[2] = {0, 0};
+    int rc = TSAR_OK;
+    if (hipMemsetAsync(dc, 0, sizeof hc, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemsetAsync failed");
+    // launches of 2^30 triples at most (~0.1 s each)
+    for (int done = 0; rc == TSAR_OK && done < (1 << (log2_triples > 30 ? log2_triples - 30 : 0)); done++)
+        rc = launch_selftest_divide_random(ctx, log2_triples > 30 ? 30 : log2_triples, seed + 0x9E3779B97F4A7C15ull * (uint64_t)done, mode, guarded, dc);
+    if (rc == TSAR_OK && hipMemcpyAsync(hc, dc, sizeof hc, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemcpyAsync failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
+    scratch.release();
+    *mismatches_out = hc[0];
+    if (outside_guard_out) *outside_guard_out = hc[1];
+    return rc;
+}

@@ -215,6 +215,8 @@ int launch_compute_disp_final(tsar_ctx* ctx, const float4* resize4, const float*
 int launch_depth_to_plane(tsar_ctx* ctx);
 int launch_getview(tsar_ctx* ctx);
 int launch_lrdiff(tsar_ctx* ctx);
+int launch_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u, float* v, int ieee);   // selftest_kernels.hip
+int launch_selftest_divide_random(tsar_ctx* ctx, int log2_pairs, uint64_t seed, int mode, int guarded, unsigned long long* dcounts);
 int launch_update_scale(tsar_ctx* ctx);
 int launch_fake_depth(tsar_ctx* ctx);
 int launch_split_out4(tsar_ctx* ctx, float* depth, float* normal3);

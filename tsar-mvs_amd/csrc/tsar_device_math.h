@@ -40,6 +40,45 @@ DEVFN float tsar_expf(float x) {
     return y * __uint_as_float((uint32_t)((int)k + 127) << 23);
 }
 
+// The perspective divide of a tap, u = X / Z and v = Y / Z (getCorrespondingPoint_cu gipuma.cu:161-171, vecdiv4), correctly rounded
+// like the oracle's two IEEE divisions but without the compiler's v_div_scale / v_div_fmas / v_div_fixup sequence (12 VALU + 1
+// transcendental per quotient): one v_rcp_f32 and one Newton step shared by both quotients, then per quotient q = n r,
+// s = n - d q (exact), q' = q + s r: 8 VALU + 1 transcendental per tap.  That q' is the correctly rounded quotient is not argued but
+// enumerated: whether it is depends on the two 23-bit mantissas only while every intermediate stays normal (scaling an operand by a
+// power of two scales every step exactly), and tools/div_exact.hip compares q' with `/` for all 2^46 mantissa pairs on the GPU this
+// runs on — 0 mismatches (profiles/r03/div_exact_all_mantissa_pairs.json; without the Newton step 47 045 pairs differ).
+// Operand guard: |X|, |Y|, |Z| in [2^-20, 2^39).  Then q in (2^-60, 2^60), r in (2^-40, 2^21), the residual s is a multiple of
+// 2^(-20 - 23 - 60 - 23) = 2^-126 (zero or normal, exactly representable) and e = 1 - d r0 a multiple of 2^-47: nothing underflows
+// or overflows.  Outside the guard (a tap on the image's zero column, a plane seen edge-on, NaN) the wave takes the IEEE division.
+// The guard is wave-uniform and compares magnitudes, not exponents: v_min3 / v_max3 over the three operands, two compares.
+#define TSAR_DIV_GUARD_LO 9.5367431640625e-07f      // 2^-20
+#define TSAR_DIV_GUARD_HI 274877906944.0f           // 2^38 (bound on the magnitudes: everything below 2^39 would do)
+DEVFN bool div_guard_ok(float X, float Y, float Z) {
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(X), __builtin_fabsf(Y)), __builtin_fabsf(Z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(X), __builtin_fabsf(Y)), __builtin_fabsf(Z));
+    // NaN operands: v_min / v_max return the other operand, so a NaN may pass — harmless, both forms then return NaN
+    return lo >= TSAR_DIV_GUARD_LO && hi <= TSAR_DIV_GUARD_HI;
+}
+DEVFN void div_pair_rcp_exact(float X, float Y, float Z, float& u, float& v) {    // operands inside the guard
+    const float r0 = __builtin_amdgcn_rcpf(Z);
+    const float r = fma_(fma_(-Z, r0, 1.0f), r0, r0);
+    const float qu = X * r, qv = Y * r;
+    u = fma_(fma_(-qu, Z, X), r, qu);
+    v = fma_(fma_(-qv, Z, Y), r, qv);
+}
+// GUARD = false: the caller has shown that every tap of the wave is inside the guard (the clamp-free tap loops: all four window
+// corners project inside the source image with Z in range, see view_cost)
+template <bool GUARD = true>
+DEVFN void persp_divide_exact(float X, float Y, float Z, float& u, float& v) {
+    div_pair_rcp_exact(X, Y, Z, u, v);
+    if (GUARD) {
+        if (__builtin_expect(__any(!div_guard_ok(X, Y, Z)), 0)) {
+            u = X / Z;
+            v = Y / Z;
+        }
+    }
+}
+
 // Philox4x32-10 counter-based generator: stateless (0 B/pixel; the reference keeps 48 B/pixel of
 // XORWOW state and re-seeds it from clock64() in every kernel, gipuma.cu:700,1077,1714).
 struct Rand4 {
@@ -103,10 +142,30 @@ DEVFN void view_vector(const DevRef& rf, int x, int y, float* v) {
 DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n4, float* H) {
     const float n[3] = {n4.x, n4.y, n4.z};
     float M[9], T[9];
+    // outer product, then every element divided by d (matdivide, config.h:139-148): nine correctly rounded quotients over one
+    // denominator — one reciprocal + Newton step, then three operations per quotient (div_pair_rcp_exact above, same enumeration);
+    // the wave takes the IEEE divisions when an operand of any lane is outside the guard (a zero component of t or n, mostly)
+    float P[9];
 #pragma unroll
-    for (int r = 0; r < 3; r++)   // outer product, then every element divided by d (matdivide, config.h:139-148)
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) M[r * 3 + c] = vw.R[r * 3 + c] - (vw.t[r] * n[c]) / n4.w;
+        for (int c = 0; c < 3; c++) P[r * 3 + c] = vw.t[r] * n[c];
+    const float d = n4.w;
+    float lo = __builtin_fabsf(d), hi = lo;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { lo = __builtin_fminf(lo, __builtin_fabsf(P[e])); hi = __builtin_fmaxf(hi, __builtin_fabsf(P[e])); }
+    if (__builtin_expect(__any(!(lo >= TSAR_DIV_GUARD_LO && hi <= TSAR_DIV_GUARD_HI)), 0)) {
+#pragma unroll
+        for (int e = 0; e < 9; e++) M[e] = vw.R[e] - P[e] / d;
+    } else {
+        const float r0 = __builtin_amdgcn_rcpf(d);
+        const float rc = fma_(fma_(-d, r0, 1.0f), r0, r0);
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            const float q = P[e] * rc;
+            M[e] = vw.R[e] - fma_(fma_(-q, d, P[e]), rc, q);
+        }
+    }
     mat3mul(M, rf.Kinv, T);
     mat3mul(vw.K, T, H);
 }

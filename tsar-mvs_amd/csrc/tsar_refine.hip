@@ -38,7 +38,7 @@ DEVFN float reverse_cost(const DevScene* __restrict__ sc, const DevView& vw, int
             const float Z = fma_(V[7], qy, fma_(V[6], qx, V[8]));
             const float X = fma_(V[1], qy, fma_(V[0], qx, V[2])), Y = fma_(V[4], qy, fma_(V[3], qx, V[5]));
             float u, v;
-            if (STRICT) { u = X / Z; v = Y / Z; }
+            if (STRICT) persp_divide_exact<true>(X, Y, Z, u, v);   // = X / Z, Y / Z bit for bit
             else { const float rz = __builtin_amdgcn_rcpf(Z); u = X * rz; v = Y * rz; }
             const float src_pix = sample_bilinear<QUAD>(rv, w, h, qp, u, v, q8);
             const float sd = sqrtf((float)(i * i + j * j));
