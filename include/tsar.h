@@ -289,6 +289,10 @@ int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, int cap, int*
 int tsar_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u_out, float* v_out, int ieee);
 int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint64_t seed, int mode, int guarded, uint64_t* mismatches_out,
                                 uint64_t* outside_guard_out);
+/* Census of the propagation arms of the NEXT half-sweep of `colour` on the current state (nothing is modified): how many multi-view
+ * evaluations the wave-uniform hypothesis loop of the sweep kernel runs, against what lane-local candidate queues would run
+ * (gipuma.cu:553-555 early-outs; selftest_kernels.hip documents the eight counters). */
+int tsar_selftest_sweep_census(tsar_ctx* ctx, int colour, uint64_t* out8);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,44 @@
+// pm_sweep_experiments.hip — dispatch of the measured-and-rejected / diagnostic tap-loop variants (pm_core_experiments.h) and of the
+// LDS-patch sweep (pm_sweep_lds.hip).  Built only with `make TSAR_EXPERIMENTS=1`; selected with TSAR_VARIANT / TSAR_LDS_SWEEP.
+#include "pm_sweep_impl.h"
+
+int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr, int* launched) {
+    *launched = 0;
+    const DevScene& hs = ctx->hscene;
+    if (ctx->lds_sweep && !ctx->final_text) {   // opt-in LDS-patch form for 8-bit imagery, box 11, n_best <= 2, <= 10 views
+        const int rc = launch_pm_sweep_lds(ctx, colour, a, b, c, sid, dp, dr, launched);
+        if (rc != TSAR_OK || *launched) return rc;
+    }
+    const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;
+    const bool strict = hs.flags & TSAR_FLAG_STRICT_DIV;
+    if (!(hs.use_quad && hs.hrad == 5 && hs.vrad == 5 && need <= 2) || (hs.flags & TSAR_FLAG_TEX_FILTER_8BIT)) return TSAR_OK;
+#define EXP(S, V) case V: *launched = 1; return launch_sweep_t<2, 5, S, true, V>(ctx, colour, a, b, c, sid, dp, dr)
+    if (strict) {
+        switch (ctx->variant) {
+            EXP(true, 58);
+            EXP(true, 50);
+            default: return TSAR_OK;
+        }
+    }
+    switch (ctx->variant) {
+        EXP(false, 762);       // 250 + gathers of line t+1 issued before line t is blended
+        EXP(false, 655610);    // buffer loads + division-free corner test
+        EXP(false, 131290);    // buffer loads, no wave priority
+        EXP(false, 393466);    // 250 + buffer loads, issued back to back
+        EXP(false, 65786);     // 250 + 64 x 8 region: 2 x 32 lanes per wave
+        EXP(false, 16634);     // 250 + 8 x 8 lanes per wave
+        EXP(false, 33018);     // 250 + 16 x 4 lanes per wave
+        EXP(false, 506);       // WRONG RESULTS: the instruction mix of pairing two taps into one 16-byte gather
+        EXP(false, 254);       // WRONG RESULTS: 250 without gathers (texel bits synthesised from the address): the VALU floor
+        EXP(false, 1048826);   // WRONG RESULTS: 250 with every gather replaced by an LDS read: the ceiling of an LDS-staged source patch
+        EXP(false, 2);
+        EXP(false, 6);
+        EXP(false, 10);
+        EXP(false, 18);
+        EXP(false, 26);
+        EXP(false, 50);
+        EXP(false, 58);
+        default: return TSAR_OK;
+    }
+#undef EXP
+}

@@ -74,3 +74,69 @@ int launch_selftest_divide_random(tsar_ctx* ctx, int log2_pairs, uint64_t seed, 
     TSAR_HIP_TRY(ctx, hipGetLastError());
     return TSAR_OK;
 }
+
+// ---- census of the sweep's hypothesis loop -----------------------------------------------------------------------------------
+// pm_sweep_kernel runs ONE rolled loop per wave over the 8 propagation arms and the R refinement steps: an arm costs a whole
+// multi-view evaluation for the wave whenever ANY of its 64 lanes has a candidate that survives the early-outs (gipuma.cu:553-555,
+// pm_sweep_impl.h: arm skipped, plane already held, depth out of range).  A lane-local queue (each lane walks its own surviving
+// candidates) would cost max-over-lanes(survivors) evaluations instead.  This kernel counts both on the context's current state with
+// the sweep's own lane -> pixel map and candidate selection, so the gain can be known before the loop is rewritten:
+//   out[0] waves with at least one pixel        out[1] sum over waves of arms with any surviving lane   (what the loop runs now)
+//   out[2] sum over waves of max-over-lanes survivors            out[3] the same with duplicate planes among a lane's own arms removed
+//   out[4] sum over lanes of survivors          out[5] the same without duplicates          out[6] pixels        out[7] arms not skipped (ci >= 0)
+#include "pm_sweep_impl.h"
+__global__ __launch_bounds__(256) void sweep_census_kernel(const DevScene* __restrict__ sc, int colour, const float* __restrict__ c, const float4* __restrict__ n4,
+                                                           int tiles_x, int cost_consistent, unsigned long long* out) {
+    const int tix = blockIdx.x % tiles_x, tiy = blockIdx.x / tiles_x;
+    const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int y = tiy * 16 + ly;
+    const int x = tix * 32 + 2 * k + ((colour + y) & 1);
+    const int w = sc->w, h = sc->h;
+    const bool live = x < w && y < h;
+    uint32_t alive = 0, alive_nodup = 0, present = 0;
+    if (live) {
+        const DevRef& rf = sc->ref;
+        int cand[8];
+        select_candidates(sc, c, c, x, y, cand);
+        const float4 n_first = n4[y * w + x];
+        float4 pl[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            if (cand[a] < 0) continue;
+            present |= 1u << a;
+            pl[a] = n4[cand[a] & 0x3fffffff];
+            if (cost_consistent && same_bits(pl[a], n_first)) continue;
+            const float d = plane_depth(rf, pl[a], x, y);
+            if (!(d >= rf.depthMin && d <= rf.depthMax)) continue;
+            alive |= 1u << a;
+            bool dup = false;
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (b < a && ((alive_nodup >> b) & 1u) && same_bits(pl[a], pl[b])) dup = true;
+            if (!dup) alive_nodup |= 1u << a;
+        }
+    }
+    // per wave
+    int arms_any = 0;
+#pragma unroll
+    for (int a = 0; a < 8; a++) arms_any += __any((alive >> a) & 1u) ? 1 : 0;
+    int mx = __popc(alive), mxn = __popc(alive_nodup), sm = mx, smn = mxn, px = live ? 1 : 0, pr = __popc(present);
+    for (int o = 32; o; o >>= 1) {
+        mx = max(mx, __shfl_xor(mx, o)); mxn = max(mxn, __shfl_xor(mxn, o));
+        sm += __shfl_xor(sm, o); smn += __shfl_xor(smn, o); px += __shfl_xor(px, o); pr += __shfl_xor(pr, o);
+    }
+    if ((threadIdx.x & 63) == 0 && px > 0) {
+        atomicAdd(&out[0], 1ull); atomicAdd(&out[1], (unsigned long long)arms_any); atomicAdd(&out[2], (unsigned long long)mx);
+        atomicAdd(&out[3], (unsigned long long)mxn); atomicAdd(&out[4], (unsigned long long)sm); atomicAdd(&out[5], (unsigned long long)smn);
+        atomicAdd(&out[6], (unsigned long long)px); atomicAdd(&out[7], (unsigned long long)pr);
+    }
+}
+
+int launch_sweep_census(tsar_ctx* ctx, int colour, unsigned long long* dout) {
+    const DevScene& hs = ctx->hscene;
+    const int tiles_x = (hs.w + 31) / 32, tiles_y = (hs.h + 15) / 16;
+    hipLaunchKernelGGL(sweep_census_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, ctx->dscene, colour, ctx->buf[0].c, ctx->buf[0].n4, tiles_x,
+                       ctx->cost_consistent ? 1 : 0, dout);
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}

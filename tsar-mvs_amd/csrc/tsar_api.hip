@@ -851,3 +851,19 @@ extern "C" int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint
     if (outside_guard_out) *outside_guard_out = hc[1];
     return rc;
 }
+extern "C" int tsar_selftest_sweep_census(tsar_ctx* ctx, int colour, uint64_t* out8) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    NEED_STATE(ctx);
+    if (!out8) return fail(ctx, TSAR_ERR_INVALID, "out8 is NULL");
+    ScratchScope scratch(ctx);
+    unsigned long long* dc = (unsigned long long*)scratch.alloc(8 * sizeof(unsigned long long));
+    if (!dc) { scratch.release(); return fail(ctx, TSAR_ERR_NOMEM, "device allocation failed"); }
+    int rc = TSAR_OK;
+    if (hipMemsetAsync(dc, 0, 64, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemsetAsync failed");
+    if (rc == TSAR_OK) rc = launch_sweep_census(ctx, colour & 1, dc);
+    if (rc == TSAR_OK && hipMemcpyAsync(out8, dc, 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemcpyAsync failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
+    scratch.release();
+    return rc;
+}

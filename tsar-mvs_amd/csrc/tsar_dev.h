@@ -206,6 +206,8 @@ static inline bool lut_path_applies(const tsar_ctx* ctx) {
     const bool d16_ok = (hs.flags & TSAR_FLAG_STRICT_DIV) || (ctx->variant & 8);
     return !off && d16_ok && hs.use_quad && hs.lut_classes > 0;
 }
+int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
+                               int do_prop, int do_refine, int* launched);   // pm_sweep_experiments.hip (TSAR_EXPERIMENTS builds)
 int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                         int do_prop, int do_refine, int* launched);
 int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio);
@@ -216,6 +218,7 @@ int launch_depth_to_plane(tsar_ctx* ctx);
 int launch_getview(tsar_ctx* ctx);
 int launch_lrdiff(tsar_ctx* ctx);
 int launch_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u, float* v, int ieee);   // selftest_kernels.hip
+int launch_sweep_census(tsar_ctx* ctx, int colour, unsigned long long* dout);
 int launch_selftest_divide_random(tsar_ctx* ctx, int log2_pairs, uint64_t seed, int mode, int guarded, unsigned long long* dcounts);
 int launch_update_scale(tsar_ctx* ctx);
 int launch_fake_depth(tsar_ctx* ctx);
