@@ -107,6 +107,11 @@ extern "C" {
                                                   unpublished: round-to-nearest-even here.  Runs the general-window tap loop at every box
                                                   (box 11: ~15 % below the default filter). */
 
+#define TSAR_FLAG_FIX_INIT_RADIUS     (1u << 6) /* tsar_pm_init on the sweeps' window, radius (box - 1) / 2.  The reference's
+                                                  gipuma_init_cu2 uses box / 2 (gipuma.cu:693-694), every other kernel
+                                                  (box - 1) / 2 (:858-859): an even box initialises on a larger window.
+                                                  Reproduced by default. */
+
 typedef struct tsar_ctx tsar_ctx;
 
 /* One calibrated view as read from an MVSNet-style cams/%08d_cam.txt (reference

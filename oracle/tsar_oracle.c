@@ -43,6 +43,7 @@
 #define ORC_FLAG_FIX_DOWN_FAR_SEED (1u << 0)
 #define ORC_FLAG_FIX_RIGHT_FAR_CMP (1u << 1)
 #define ORC_FLAG_TEX_FILTER_8BIT (1u << 5)
+#define ORC_FLAG_FIX_INIT_RADIUS (1u << 6) /* gipuma_init_cu2 on the sweeps' window instead of its own box / 2 (gipuma.cu:693-694) */
 
 typedef struct {
     float K[9], Kinv[9], R[9], t[3]; /* pose relative to the reference camera (ref = K[I|0]) */
@@ -57,6 +58,7 @@ typedef struct {
     orc_camera cam[ORC_MAX_VIEWS];
     int n_sel, sel[ORC_MAX_VIEWS];
     int hrad, vrad, n_best, cost_comb;
+    int box_hsize, box_vsize;   /* as given: gipuma_init_cu2 derives its own radius from them */
     float min_disp, max_disp;
     uint32_t flags;
     uint64_t seed;
@@ -388,9 +390,14 @@ static void init_pixel(orc_state *s, int x, int y) {
     s->c[p] = pm_cost_multiview(s, x, y, n4, &bv, &rt);
 }
 void orc_pm_init(orc_state *s) {
+    /* gipuma_init_cu2 takes box / 2 as its window radius (gipuma.cu:693-694); the propagation, refinement and lrdiff kernels
+     * take (box - 1) / 2 (:858-859, :1065-1066, :1175-1176).  They differ for even boxes. */
+    const int hr = s->hrad, vr = s->vrad;
+    if (!(s->flags & ORC_FLAG_FIX_INIT_RADIUS)) { s->hrad = s->box_hsize / 2; s->vrad = s->box_vsize / 2; }
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < s->h; y++)
         for (int x = 0; x < s->w; x++) init_pixel(s, x, y);
+    s->hrad = hr; s->vrad = vr;
     s->launch = 0;
 }
 
@@ -774,7 +781,7 @@ orc_state *orc_create(int w, int h) {
     s->depth = (float *)calloc(np, 4); s->scale = (float *)calloc(np, 4); s->lrdiff = (float *)calloc(np, 4);
     s->confid = (float *)calloc(np, 4); s->fakedepth = (float *)calloc(np, 4);
     s->beview = (int32_t *)calloc(np, 4); s->canny = (int32_t *)calloc(np, 4);
-    s->n_best = 1; s->cost_comb = 1; s->hrad = 5; s->vrad = 5;
+    s->n_best = 1; s->cost_comb = 1; s->hrad = 5; s->vrad = 5; s->box_hsize = 11; s->box_vsize = 11;
     return s;
 }
 void orc_destroy(orc_state *s) {
@@ -787,6 +794,7 @@ void orc_destroy(orc_state *s) {
 void orc_set_image(orc_state *s, int view, const float *img) { s->img[view] = img; } /* borrowed */
 void orc_set_params(orc_state *s, int box_hsize, int box_vsize, int n_best, int cost_comb, uint32_t flags, uint64_t seed) {
     s->hrad = (box_hsize - 1) / 2; s->vrad = (box_vsize - 1) / 2; /* gipuma.cu:858-859 */
+    s->box_hsize = box_hsize; s->box_vsize = box_vsize;
     s->n_best = n_best; s->cost_comb = cost_comb; s->flags = flags; s->seed = seed;
 }
 void orc_set_subset(orc_state *s, int n, const int32_t *idx) {

@@ -1,0 +1,167 @@
+"""Taps on and beyond the border of a source image, and behind the camera — the addressing edge behind round 2's abort.
+
+What happened (gpurun_out/t_r2c.log, round 2): while the quad-texture base was being moved into an SGPR pair with an UNSIGNED
+per-tap offset from entry (1, 1), strict mode still clamped tap positions to the oracle's [-1, w].  A tap with u in [-1, 0) then
+has floor(u) = -1, its element index iv * pitch + iu became negative, the unsigned byte offset wrapped to ~4 GiB and the gather
+left the allocation: a GPU memory fault, reported as `Fatal Python error: Aborted` inside tsar_pm_cost_planes
+(tests/test_golden.py, whose ground-truth planes put border windows half a pixel outside a source view).  Fixed in the next commit:
+positions are clamped to [0, w - 1] (the same sample bit for bit: with edge replication both texels of the pair are the edge
+texel), and the clamp-free loop keeps a pixel of margin (pm_tap_r5.h).  The production fast path has since moved to range-checked
+buffer loads, which would turn the same slip into silent zeros instead of a fault — so this test pins the edge in every form:
+strict and fast arithmetic, global-load and buffer-load gathers (the two must agree BIT FOR BIT), the every-pixel kernel and the
+sweep kernel, against the CPU oracle.
+
+Construction: reference camera at the origin, three source cameras that differ by a pure translation along x, y and z; for a
+fronto-parallel plane at depth Z0 the homography is then the shift u = x + f tx / Z0 (v likewise), or a point reflection with
+Z = 1 + tz / Z0 < 0.  Z0 is chosen so that the outermost taps of the border pixels' windows land at the wanted offsets."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from tsar_mvs_amd import api
+
+pytestmark = pytest.mark.gpu
+
+W, H, F = 96, 64, 100.0
+TX, TY = 0.1, 0.1
+# tap offset (pixels) of the window's outermost column / row relative to the border texel: inside [-1, 0), exactly -1, beyond -1
+# (the oracle clamps to [-1, w]), a hair below 0, and the same on the far side through the sign
+SHIFTS = [-0.5, -0.999, -1.0, -1.5, -3.25, -1e-4, 0.5, 0.999, 1.0, 1.5, 3.25, 1e-4]
+
+
+def _scene():
+    rng = np.random.default_rng(31)
+    base = rng.integers(0, 256, size=(H + 16, W + 16)).astype(np.float32)
+    imgs = [base[8:8 + H, 8:8 + W].copy(), base[8:8 + H, 9:9 + W].copy(), base[9:9 + H, 8:8 + W].copy(), base[7:7 + H, 8:8 + W].copy()]
+    K = np.tile(np.array([[F, 0, W / 2], [0, F, H / 2], [0, 0, 1]], np.float32), (4, 1, 1))
+    R = np.tile(np.eye(3, dtype=np.float32), (4, 1, 1))
+    t = np.array([[0, 0, 0], [TX, 0, 0], [0, TY, 0], [0.01, 0.02, -1.0]], np.float32)
+    return imgs, K, R, t
+
+
+def _plane_map(z0):
+    p = np.zeros((H, W, 4), np.float32)
+    p[..., 2] = -1.0
+    p[..., 3] = z0                      # n . X + d = 0 with n = (0, 0, -1): the plane Z = z0
+    return p
+
+
+def _cases():
+    out = []
+    for s in SHIFTS:
+        out.append((1, F * TX / s))     # view 1: u = x + s; a negative depth is a legal plane for pm_cost_planes (Z = 1 here)
+        out.append((2, F * TY / s))     # view 2: v = y + s
+    out += [(3, 0.5), (3, 0.9), (3, 0.999)]     # view 3: Z = 1 - 1 / z0 < 0 (behind the source camera), and barely negative
+    return out
+
+
+def _matcher(flags, buffer_gather):
+    old = os.environ.get("TSAR_BUFFER_GATHER")
+    os.environ["TSAR_BUFFER_GATHER"] = "1" if buffer_gather else "0"       # read by tsar_create
+    try:
+        m = api.Matcher()
+    finally:
+        if old is None:
+            os.environ.pop("TSAR_BUFFER_GATHER")
+        else:
+            os.environ["TSAR_BUFFER_GATHER"] = old
+    imgs, K, R, t = _scene()
+    m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=1e-3, depth_max=1e6, seed=3, flags=flags))
+    m.set_views(imgs, K, R, t)
+    return m
+
+
+def _sweep_cost(m, planes):
+    """cost of `planes` as the SWEEP kernel scores them: every pixel holds MAXCOST and the same plane as all its neighbours, so a
+    propagation-only sweep of both colours leaves c[p] = cost(plane at p).  Sweep counter 2: the launcher's buffer-load form
+    (when the context allows it)."""
+    m.set_plane(planes, np.full((H, W), 2.0, np.float32))
+    m.set_sweep_counter(2)
+    m.pm_sweep(0, do_prop=True, do_refine=False)
+    m.pm_sweep(1, do_prop=True, do_refine=False)
+    return m.get_plane()[1]
+
+
+@pytest.fixture
+def block_shape(request):
+    """TSAR_BLOCK (read per launch): the sweep's 128-thread workgroups (what an image this small gets) or the 256-thread shape of
+    full-size images"""
+    old = os.environ.get("TSAR_BLOCK")
+    os.environ["TSAR_BLOCK"] = str(request.param)
+    yield request.param
+    if old is None:
+        os.environ.pop("TSAR_BLOCK")
+    else:
+        os.environ["TSAR_BLOCK"] = old
+
+
+@pytest.mark.parametrize("block_shape", [128, 256], indirect=True)
+@pytest.mark.parametrize("strict", [True, False])
+def test_border_and_behind_camera_taps_all_gather_forms(strict, block_shape):
+    imgs, K, R, t = _scene()
+    flags = api.FLAG_STRICT_DIV if strict else 0
+    mb, mg = _matcher(flags, True), _matcher(flags, False)
+    n_border_pixels = 0
+    for view, z0 in _cases():
+        if z0 < 0 and view != 3:
+            continue                    # (negative shifts are produced by the sign of the shift below, not of the depth)
+        planes = _plane_map(np.float32(z0))
+        orc = ol.Oracle(imgs, K, R, t, 1e-3, 1e6, box=11, n_best=1, seed=3, subset=[view])
+        c_ref = orc.pm_cost_planes(planes)[0]
+        res = {}
+        for name, m in (("buffer", mb), ("global", mg)):
+            m.set_view_subset([view])
+            res[name + "_full"] = m.pm_cost_planes(planes)[0]
+            res[name + "_sweep"] = _sweep_cost(m, planes)
+        # the two gather forms, and the two kernels, agree bit for bit in either arithmetic
+        for k in ("buffer_sweep", "global_full", "global_sweep"):
+            assert np.array_equal(res["buffer_full"], res[k]), (view, z0, k)
+        if strict:
+            assert np.array_equal(res["buffer_sweep"], c_ref), (view, z0)
+        elif view != 3:
+            assert np.max(np.abs(res["buffer_sweep"] - c_ref)) <= 1e-3, (view, z0)
+        else:
+            # the reflection through Z < 0 magnifies positions ~10x on a white-noise image and throws most taps onto the clamped
+            # border, where var_src hovers around the 1e-5 threshold that switches the cost to MAXCOST (gipuma.cu:289-291): fast
+            # arithmetic may legitimately land on the other side of that switch, so only the bulk is compared here — the bit-level
+            # statement for this case is the strict run and the equality of the gather forms above
+            assert np.median(np.abs(res["buffer_sweep"] - c_ref)) <= 1e-3, (view, z0)
+        n_border_pixels += int((c_ref < 2.0).sum())
+    assert n_border_pixels > 1000        # the cases score real windows, not MAXCOST everywhere
+    mb.close(); mg.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_negative_shifts(strict):
+    """the same with the cameras mirrored (tx, ty < 0): taps beyond the LEFT and TOP borders (u, v in [-1, 0) and below) — the
+    side on which the unsigned offset wrapped"""
+    imgs, K, R, t = _scene()
+    t = t.copy()
+    t[1, 0], t[2, 1] = -TX, -TY
+    flags = api.FLAG_STRICT_DIV if strict else 0
+    ms = []
+    for bg in (True, False):
+        m = _matcher(flags, bg)
+        m.set_views(imgs, K, R, t)
+        ms.append(m)
+    for s in SHIFTS:
+        if s < 0:
+            continue
+        for view, z0 in ((1, F * TX / s), (2, F * TY / s)):      # u = x - s, v = y - s
+            planes = _plane_map(np.float32(z0))
+            orc = ol.Oracle(imgs, K, R, t, 1e-3, 1e6, box=11, n_best=1, seed=3, subset=[view])
+            c_ref = orc.pm_cost_planes(planes)[0]
+            got = []
+            for m in ms:
+                m.set_view_subset([view])
+                got += [m.pm_cost_planes(planes)[0], _sweep_cost(m, planes)]
+            for g in got[1:]:
+                assert np.array_equal(got[0], g), (view, s)
+            if strict:
+                assert np.array_equal(got[0], c_ref), (view, s)
+            else:
+                assert np.max(np.abs(got[0] - c_ref)) <= 1e-3, (view, s)
+    for m in ms:
+        m.close()

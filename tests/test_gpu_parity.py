@@ -135,15 +135,28 @@ def test_float_image_path_matches_quad_path(small_scene):
     assert np.mean(c_f != c_quad) < 0.2
 
 
-def test_init_strict_bit_exact(small_scene):
+# even boxes: gipuma_init_cu2 runs on radius box / 2 (gipuma.cu:693-694), the sweeps on (box - 1) / 2 (:858-859) — box 12 initialises
+# on the general-window loop (radius 6) and sweeps on the box-11 loop, box 10 the other way round, (8, 11) differs on one axis only
+@pytest.mark.parametrize("box,flags", [(11, 0), (12, 0), (10, 0), (12, api.FLAG_FIX_INIT_RADIUS), ((8, 11), 0), (20, 0), (2, 0)])
+def test_init_strict_bit_exact(small_scene, box, flags):
     sc = small_scene
-    orc = _oracle(sc, seed=77)
+    box, box_v = box if isinstance(box, tuple) else (box, box)
+    orc = _oracle(sc, seed=77, box=box, box_v=box_v, flags=flags)
     orc.pm_init()
-    m = api.matcher_from_scene(sc, seed=77, flags=api.FLAG_STRICT_DIV)
+    m = api.matcher_from_scene(sc, seed=77, box=box, box_v=box_v, flags=flags | api.FLAG_STRICT_DIV)
     m.pm_init()
     planes, cost, _, _ = m.get_plane()
     assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
     assert np.array_equal(cost, orc.c)
+    if box % 2 == 0 or box_v % 2 == 0:
+        # and the sweeps that follow run on the smaller window, from a state whose costs were NOT computed on it: a neighbour's
+        # identical plane may score lower than the stored cost, so nothing may be skipped as "already held"
+        orc.pm_iterate(1)
+        m.pm_iterate(1)
+        planes, cost, bv, _ = m.get_plane()
+        assert np.array_equal(cost, orc.c)
+        assert np.array_equal(planes.view(np.uint32), orc.norm4.view(np.uint32))
+        assert np.array_equal(bv, orc.beview)
     m.close()
 
 

@@ -254,6 +254,27 @@ def test_8bit_filter_mode_changes_costs_slightly(small_scene):
     assert 0 < d.max() < 0.05 and np.median(d) < 2e-3       # same matcher, marginally different samples
 
 
+def test_init_window_radius_is_box_over_two(small_scene):
+    """gipuma_init_cu2 derives its window radius as box / 2 (gipuma.cu:693-694), every other kernel as (box - 1) / 2 (:858-859,
+    :1065-1066, :1175-1176).  An even box therefore initialises on the window of the next odd box and sweeps on the window of the
+    previous one: box 12 -> init like box 13 (radius 6), cost evaluation like box 11 (radius 5)."""
+    sc = small_scene
+    args = ([im.numpy() for im in sc.images], sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max)
+    o12, o13, o11 = (ol.Oracle(*args, box=b, seed=9) for b in (12, 13, 11))
+    o12fix = ol.Oracle(*args, box=12, seed=9, flags=64)          # ORC_FLAG_FIX_INIT_RADIUS
+    for o in (o12, o13, o11, o12fix):
+        o.pm_init()
+    assert np.array_equal(o12.norm4.view(np.uint32), o13.norm4.view(np.uint32))      # the random planes do not depend on the window
+    assert np.array_equal(o12.c, o13.c) and not np.array_equal(o12.c, o11.c)
+    assert np.array_equal(o12fix.c, o11.c)
+    planes = o12.norm4.copy()
+    assert np.array_equal(o12.pm_cost_planes(planes)[0], o11.pm_cost_planes(planes)[0])   # everything after init: radius 5
+    # rectangular: each axis on its own
+    oa, ob = ol.Oracle(*args, box=8, box_v=11, seed=9), ol.Oracle(*args, box=9, box_v=11, seed=9)
+    oa.pm_init(); ob.pm_init()
+    assert np.array_equal(oa.c, ob.c)
+
+
 def test_refinement_step_count(small_scene):
     o = _orc(small_scene)
     n, dz = 0, o.max_disp / 2

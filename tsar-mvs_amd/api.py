@@ -22,6 +22,7 @@ COMB_ALL, COMB_BEST_N, COMB_ANGLE, COMB_GOOD = 0, 1, 2, 3
 FLAG_FIX_DOWN_FAR_SEED, FLAG_FIX_RIGHT_FAR_CMP, FLAG_STRICT_DIV = 1, 2, 4
 FLAG_NO_LINE_CLOSING = 16
 FLAG_TEX_FILTER_8BIT = 32
+FLAG_FIX_INIT_RADIUS = 64
 MAXCOST = 2.0
 MAX_VIEWS = 64
 

@@ -180,11 +180,19 @@ static void derive_cameras(tsar_ctx* ctx, const tsar_camera* cams) {
     sc.refine_steps = steps;
 }
 
-static void fill_scene_params(tsar_ctx* ctx) {
+// gipuma_init_cu2 takes its window radius as box / 2 (gipuma.cu:693-694) where every other kernel takes (box - 1) / 2
+// (:858-859, :1065-1066, :1175-1176): an even --blocksize initialises on a window one tap ring larger than the one it sweeps with.
+// Reproduced by default; TSAR_FLAG_FIX_INIT_RADIUS initialises on the sweeps' window.
+static bool init_window_differs(const tsar_ctx* ctx) {
+    const tsar_params& p = ctx->params;
+    return !(p.flags & TSAR_FLAG_FIX_INIT_RADIUS) && (p.box_hsize / 2 != (p.box_hsize - 1) / 2 || p.box_vsize / 2 != (p.box_vsize - 1) / 2);
+}
+static void fill_scene_params(tsar_ctx* ctx, bool for_init = false) {
     DevScene& sc = ctx->hscene;
     const tsar_params& p = ctx->params;
-    sc.hrad = (p.box_hsize - 1) / 2;   // gipuma.cu:858-859
-    sc.vrad = (p.box_vsize - 1) / 2;
+    const bool init_radius = for_init && !(p.flags & TSAR_FLAG_FIX_INIT_RADIUS);
+    sc.hrad = init_radius ? p.box_hsize / 2 : (p.box_hsize - 1) / 2;   // gipuma.cu:693-694 : gipuma.cu:858-859
+    sc.vrad = init_radius ? p.box_vsize / 2 : (p.box_vsize - 1) / 2;
     sc.n_best = p.n_best;
     sc.cost_comb = p.cost_comb;
     sc.flags = p.flags;
@@ -375,7 +383,8 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     if (!lut_path_applies(ctx)) {
         // float imagery keeps the hoisted bilateral weights per thread in LDS, (hrad+1)(vrad+1) taps x
         // 256 threads x 4 B beside the reference window; 8-bit imagery shares one table per workgroup (pm_core_lut.h): any box
-        const size_t lds = (size_t)(sc.hrad + 1) * (sc.vrad + 1) * 1024 + (size_t)(32 + 2 * sc.hrad) * (16 + 2 * sc.vrad) * 4 + 16;
+        const int hr_ = init_window_differs(ctx) ? ctx->params.box_hsize / 2 : sc.hrad, vr_ = init_window_differs(ctx) ? ctx->params.box_vsize / 2 : sc.vrad;   // the larger of the two windows
+        const size_t lds = (size_t)(hr_ + 1) * (vr_ + 1) * 1024 + (size_t)(32 + 2 * hr_) * (16 + 2 * vr_) * 4 + 16;
         if (lds > 160 * 1024)
             return fail(ctx, TSAR_ERR_INVALID, "box too large for images that are not 8-bit: the per-thread weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
     }
@@ -420,12 +429,25 @@ extern "C" int tsar_pm_init(tsar_ctx* ctx) {
     CHECK_CTX(ctx);
     NEED_VIEWS(ctx);
     NEED_SOURCES(ctx);
-    TRY(launch_pm_init(ctx));
-    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const bool own_window = init_window_differs(ctx);
+    if (own_window) {                      // an even box: the scene block describes the init window for this one launch
+        fill_scene_params(ctx, true);
+        TRY(upload_scene(ctx));
+    }
+    int rc = launch_pm_init(ctx);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
+    if (own_window) {
+        fill_scene_params(ctx, false);
+        const int rc2 = upload_scene(ctx);
+        if (rc == TSAR_OK) rc = rc2;
+    }
+    TRY(rc);
     ctx->have_state = true;
     ctx->have_out = false;
     ctx->sweeps_done = 0;
-    ctx->cost_consistent = true;
+    // c[p] is the score of n4[p] on the SWEEP window only if init ran on that window: otherwise a neighbour's identical plane may
+    // well score lower than the stored cost, and the sweeps must not skip it
+    ctx->cost_consistent = !own_window;
     return TSAR_OK;
 }
 
