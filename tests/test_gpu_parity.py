@@ -584,12 +584,18 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
 
 @pytest.mark.parametrize("knob,value", [("TSAR_RANSAC_CHAIN", "8"), ("TSAR_RANSAC_CHAIN", "4"), ("TSAR_RANSAC_CHAIN", "16"),
                                         ("TSAR_RANSAC_WGS", "1"), ("TSAR_RANSAC_WGS", "2"), ("TSAR_RANSAC_WGS", "4"), ("TSAR_RANSAC_WGS", "7"),
-                                        ("TSAR_RANSAC_LOOKAHEAD", "1"), ("TSAR_RANSAC_LOOKAHEAD", "2"), ("TSAR_RANSAC_LOOKAHEAD", "3")])
+                                        ("TSAR_RANSAC_LOOKAHEAD", "1"), ("TSAR_RANSAC_LOOKAHEAD", "2"), ("TSAR_RANSAC_LOOKAHEAD", "3"),
+                                        ("TSAR_RANSAC_WGS+TSAR_RANSAC_CHAIN", "1+4"), ("TSAR_RANSAC_WGS+TSAR_RANSAC_CHAIN", "1+16"),
+                                        ("TSAR_RANSAC_FORCE_FALLBACK", "1"), ("TSAR_RANSAC_POLL_LIMIT", "0"), ("TSAR_RANSAC_COOPERATIVE", "0")])
 def test_ransac_regions_bit_exact(mid_scene, monkeypatch, knob, value):
     """how stage 2 shares passes over the points between perturbation steps (ransac_kernels.hip): a speculative chain of K steps
-    (the default, K = 8) or a tree of the accept / reject histories of G steps; every setting must replay the reference's
-    sequential accept order exactly"""
-    monkeypatch.setenv(knob, value)
+    (the default, K = 8; TSAR_RANSAC_CHAIN picks the length in the multi-workgroup kernel, with TSAR_RANSAC_WGS=1 in the
+    single-workgroup one) or a tree of the accept / reject histories of G steps; every setting must replay the reference's
+    sequential accept order exactly.  TSAR_RANSAC_FORCE_FALLBACK=1 / TSAR_RANSAC_POLL_LIMIT=0: the give-up path of the
+    multi-workgroup kernel (flag pre-set / raised by the first workgroup that has to wait) — the single-workgroup kernel then
+    produces the same bits.  TSAR_RANSAC_COOPERATIVE=0: a plain launch instead of the cooperative one."""
+    for k, v in zip(knob.split("+"), value.split("+")):
+        monkeypatch.setenv(k, v)
     sc = mid_scene
     h, w = sc.h, sc.w
     orc, m = _prepared_pair(sc, 12)
@@ -625,6 +631,47 @@ def test_ransac_regions_bit_exact(mid_scene, monkeypatch, knob, value):
     res = m.get_result()
     assert np.array_equal(res["depth"], ref[..., 3])
     m.close()
+
+
+def test_ransac_two_contexts_share_the_device(mid_scene):
+    """two contexts on one device (tsar_gipuma --workers=2, two ranks sharing a GPU) fit their regions at the same time: the
+    multi-workgroup stage 2 needs its workgroups resident together, which a neighbour's kernels can prevent — the cooperative
+    launch (or, failing that, the bounded wait and the single-workgroup kernel) must give the same planes without stalling"""
+    import threading
+    import time
+    sc = mid_scene
+    labels = sc.gt_prim.numpy().astype(np.int32)
+    text = np.array([1.0, -1.0, -1.0], np.float32)
+    size = np.array([(labels == k).sum() for k in range(3)], np.float32)
+    gt = sc.gt_depth.numpy()
+    pairs = [_prepared_pair(sc, 12) for _ in range(2)]
+    for orc, m in pairs:
+        d = orc.compute_disp()[..., 3]
+        scale = (np.abs(d - gt) / gt < 0.01).astype(np.float32)
+        orc.scale[:] = scale
+        m.set_reliable_mask(scale)
+        orc.set_regions(labels, text, size)
+        m.set_regions(labels, text, size)
+    planes_ref, ratio_ref = pairs[0][0].ransac_regions()
+    out = [[], []]
+
+    def work(k):
+        for _ in range(6):
+            out[k].append(pairs[k][1].ransac_regions())        # ctypes releases the GIL: the two contexts' kernels overlap
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for k in range(2):
+        for planes, ratio in out[k]:
+            assert np.array_equal(planes[1:].view(np.uint32), planes_ref[1:].view(np.uint32)) and np.array_equal(ratio, ratio_ref)
+    assert dt < 5.0, "12 region fits took %.1f s: a spin barrier ran into its limit" % dt     # ~0.1 s when nothing stalls
+    for _, m in pairs:
+        m.close()
 
 
 @pytest.mark.parametrize("S,iters,conn,space", [(20, 5, 0, 0), (16, 3, 1, 0), (20, 2, 0, 1), (12, 2, 1, 2)])

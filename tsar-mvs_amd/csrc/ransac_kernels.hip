@@ -451,8 +451,11 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_kernel(const flo
 // (three rotate: workgroup 0 clears the next one before it arrives at the barrier, a pass after its last reader left) and waits
 // at a per-region arrival counter until all W have added.  ~540 passes per region, a few microseconds of barrier each, against
 // 33 us of counting per pass on one CU.  The W workgroups of a region must be resident together: the host launches at most
-// one 1024-thread workgroup per CU, and a wait that does not end within ~2^22 polls raises `failed` (every workgroup then
-// leaves) and the host runs the single-workgroup kernel instead — a spin can never hang the device.
+// one 1024-thread workgroup per CU AS A COOPERATIVE LAUNCH (hipLaunchCooperativeKernel: the runtime places the whole grid or
+// refuses the launch, also when another context's kernels hold CUs of the device), and as a second line a wait that does not end
+// within `poll_limit` polls (~10 ms by default; a pass is microseconds) raises `failed`: every workgroup then leaves and the host
+// runs the single-workgroup kernel instead — a spin can never hang the device.  A workgroup that finds `failed` set when it
+// starts leaves at once (TSAR_RANSAC_FORCE_FALLBACK=1 pre-sets it: the test of the give-up path).
 // sync[slot]: [0] arrival counter, [1 .. 3 K] the three accumulators.
 #define RS_SYNC_INTS 64
 template <int K>
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_mw_kernel(const 
                                                                           const int* __restrict__ pts_count, const int* __restrict__ region_of_slot,
                                                                           uint32_t k0, uint32_t k1, uint32_t flags, const RansacState* __restrict__ state,
                                                                           const int* __restrict__ cnt_all, float4* __restrict__ region_n4,
-                                                                          float* __restrict__ inlier_ratio, int W, int* sync_all, int* failed) {
+                                                                          float* __restrict__ inlier_ratio, int W, int* sync_all, int* failed, int poll_limit) {
     static_assert(1 + 3 * K <= RS_SYNC_INTS, "sync block too small");
     __shared__ int sh[RS_BLOCK / 64], sh2[RS_BLOCK / 64];
     __shared__ int shb[RS_BLOCK / 64][K];
@@ -474,8 +477,8 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_mw_kernel(const 
     const int i0 = (int)(((long long)n * wg) / W), i1 = (int)(((long long)n * (wg + 1)) / W);
     int* sync = sync_all + (size_t)slot * RS_SYNC_INTS;
     RansacState st = state[slot];
-    bool ok = true;
-    if (n > 0) {
+    bool ok = __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;   // (uniform: nobody waits for a workgroup that left)
+    if (n > 0 && ok) {
         {   // the last phase of stage 1 still has to be replayed (every workgroup, identically)
             int best_cnt;
             const int ix = replay_phase(cnt_all + (size_t)slot * RS_PHASE, st.maximum, sh, sh2, &best_cnt);
@@ -513,8 +516,8 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_refine_chain_mw_kernel(const 
                 int polls = 0, bad = 0;
                 while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(4);
-                    if ((++polls & 1023) == 0 && __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = 1; break; }
-                    if (polls > (1 << 22)) { __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
+                    if ((++polls & 255) == 0 && __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = 1; break; }
+                    if (polls > poll_limit) { __hip_atomic_store(failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
                 }
                 give_up = bad;
             }
@@ -674,12 +677,34 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                 if (!d_sync) return done(TSAR_ERR_NOMEM, "hipMalloc failed");
                 int* d_failed = d_sync + (size_t)nslot * RS_SYNC_INTS;
                 hipMemsetAsync(d_sync, 0, (size_t)nslot * RS_SYNC_INTS * 4 + 4, st);
-                hipLaunchKernelGGL(ransac_refine_chain_mw_kernel<8>, dim3(nslot * wgs), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot,
-                                   ctx->hscene.seed_lo, ctx->hscene.seed_hi, ctx->hscene.flags, d_state, d_cnt, ctx->region_n4, d_ratio, wgs, d_sync, d_failed);
-                int h_failed = 1;
-                hipMemcpyAsync(&h_failed, d_failed, 4, hipMemcpyDeviceToHost, st);
-                if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "ransac kernel failed");
-                fitted = h_failed == 0;                       // else: the workgroups were not resident together; one per region below
+                // diagnostics: TSAR_RANSAC_FORCE_FALLBACK=1 pre-sets `failed` (the give-up path: every workgroup leaves, the
+                // single-workgroup kernel below produces the result); TSAR_RANSAC_POLL_LIMIT=n bounds a wait (default 2^15 polls
+                // of ~0.3 us: ~10 ms, three orders of magnitude above a pass)
+                const bool force_fallback = getenv("TSAR_RANSAC_FORCE_FALLBACK") && getenv("TSAR_RANSAC_FORCE_FALLBACK")[0] == '1';
+                int poll_limit = getenv("TSAR_RANSAC_POLL_LIMIT") ? atoi(getenv("TSAR_RANSAC_POLL_LIMIT")) : (1 << 15);
+                if (force_fallback) { const int one = 1; hipMemcpyAsync(d_failed, &one, 4, hipMemcpyHostToDevice, st); }
+                const void* mw = chain == 4 ? (const void*)ransac_refine_chain_mw_kernel<4> : (chain == 16 ? (const void*)ransac_refine_chain_mw_kernel<16> : (const void*)ransac_refine_chain_mw_kernel<8>);
+                const float* a_pts = d_pts; const int *a_ps = d_pts_start, *a_pc = d_pts_count, *a_rs = d_region_of_slot, *a_cnt = d_cnt;
+                uint32_t a_k0 = ctx->hscene.seed_lo, a_k1 = ctx->hscene.seed_hi, a_fl = ctx->hscene.flags;
+                const RansacState* a_state = d_state;
+                float4* a_n4 = ctx->region_n4;
+                float* a_ratio = d_ratio;
+                int a_w = wgs;
+                void* args[] = {&a_pts, &a_ps, &a_pc, &a_rs, &a_k0, &a_k1, &a_fl, &a_state, &a_cnt, &a_n4, &a_ratio, &a_w, &d_sync, &d_failed, &poll_limit};
+                int coop = 0;
+                if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device) != hipSuccess) coop = 0;
+                if (getenv("TSAR_RANSAC_COOPERATIVE") && getenv("TSAR_RANSAC_COOPERATIVE")[0] == '0') coop = 0;
+                hipError_t le = coop ? hipLaunchCooperativeKernel(mw, dim3(nslot * wgs), dim3(RS_BLOCK), args, 0, st)
+                                     : hipLaunchKernel(mw, dim3(nslot * wgs), dim3(RS_BLOCK), args, 0, st);
+                if (le == hipSuccess) {
+                    int h_failed = 1;
+                    hipMemcpyAsync(&h_failed, d_failed, 4, hipMemcpyDeviceToHost, st);
+                    if (hipStreamSynchronize(st) != hipSuccess) return done(TSAR_ERR_HIP, "ransac kernel failed");
+                    fitted = h_failed == 0;                   // else: the workgroups were not resident together; one per region below
+                } else {
+                    (void)hipGetLastError();                  // the grid could not be placed as a whole (or no cooperative launches here): one workgroup per region below
+                }
+                if (trace) fprintf(stderr, "[ransac] stage 2 on %d workgroups per region: %s%s\n", wgs, coop ? "cooperative launch" : "plain launch", fitted ? "" : " -> fallback to one workgroup per region");
             }
             if (!fitted)
                 hipLaunchKernelGGL(refine, dim3(nslot), dim3(RS_BLOCK), 0, st, d_pts, d_pts_start, d_pts_count, d_region_of_slot, ctx->hscene.seed_lo,

@@ -345,10 +345,12 @@ extern "C" int tsar_wmf(tsar_ctx* ctx, int iters, int final_pass) {
     if (iters < 1 || iters > (final_pass ? 6 : 4)) { ctx->err = "tsar_wmf: iters must be 1..4 (detect) or 1..6 (final)"; return TSAR_ERR_INVALID; }
     if (final_pass && ctx->n_regions < 1) { ctx->err = "tsar_set_regions has not been called"; return TSAR_ERR_STATE; }
     const size_t np = (size_t)ctx->w * ctx->h;
-    float *scale_snap = nullptr, *depth_snap = nullptr;
-    if (hipMalloc((void**)&scale_snap, np * 4) != hipSuccess || (final_pass && hipMalloc((void**)&depth_snap, np * 4) != hipSuccess)) {
-        hipFree(scale_snap);
-        ctx->err = "hipMalloc failed";
+    ScratchScope scratch(ctx);             // the launch-start snapshots come out of the context's scratch arena
+    float* scale_snap = (float*)scratch.alloc(np * 4);
+    float* depth_snap = final_pass ? (float*)scratch.alloc(np * 4) : nullptr;
+    if (!scale_snap || (final_pass && !depth_snap)) {
+        scratch.release();
+        ctx->err = "device allocation failed";
         return TSAR_ERR_NOMEM;
     }
     const dim3 grid((unsigned)((np + WMF_BLOCK - 1) / WMF_BLOCK)), block(WMF_BLOCK);
@@ -368,8 +370,7 @@ extern "C" int tsar_wmf(tsar_ctx* ctx, int iters, int final_pass) {
         if (hipGetLastError() != hipSuccess) { ctx->err = "wmf launch failed"; rc = TSAR_ERR_HIP; }
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) { ctx->err = "wmf kernel failed"; rc = TSAR_ERR_HIP; }
-    hipFree(scale_snap);
-    hipFree(depth_snap);
+    scratch.release();
     ctx->have_out = false;
     if (final_pass) ctx->cost_consistent = false;
     return rc;
