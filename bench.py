@@ -157,7 +157,7 @@ def strict_mode_record(args, sc, local_rank):
     from tsar_mvs_amd import api
     m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024, device=local_rank, flags=api.FLAG_STRICT_DIV)
     m.enable_kernel_timing(True)
-    steps = 2
+    steps = args.steps                  # the same number of timed steps as the headline
 
     def one():
         m.pm_init()
@@ -174,7 +174,7 @@ def strict_mode_record(args, sc, local_rank):
     timing = m.kernel_timing()
     m.close()
     rec = {"value": args.width * args.height * steps / dt / 1e6, "unit": "Mpix/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
-           "note": "TSAR_FLAG_STRICT_DIV: IEEE divides and the oracle's operation order, bit-identical to the CPU oracle"}
+           "note": "TSAR_FLAG_STRICT_DIV: correctly rounded divides and the oracle's operation order, bit-identical to the CPU oracle (the mode every bit-exact parity test runs)"}
     if "pm_sweep" in timing and timing["pm_sweep"][0] > 0:
         rec["pm_sweep_avg_launch_ms"] = timing["pm_sweep"][1] / timing["pm_sweep"][0]
     return rec

@@ -125,9 +125,12 @@ typedef struct tsar_camera {
 /* Subset of the reference's AlgorithmParameters (algorithmparameters.h:54-88) that the GPU path
  * reads.  Zero-initialise, then tsar_default_params(). */
 typedef struct tsar_params {
-    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19).  1..63; images that are not an 8-bit decode:
-                             tsar_set_views refuses boxes whose per-thread weight table exceeds
-                             the LDS (largest square box 23) */
+    int32_t box_hsize;    /* --blocksize (scripts pass 11; default 19).  1..63.  tsar_set_views refuses (TSAR_ERR_INVALID, with the
+                             reason in tsar_last_error) a box above 23 when the shared weight table of the general-window loop
+                             cannot serve it: images that are not an 8-bit decode; rectangular boxes with more than 144 distinct
+                             tap distances (radii of mixed parity, e.g. 63 x 61); fast mode on a device whose D16 LDS-load probe
+                             failed.  An even box initialises on radius box / 2 and sweeps on (box - 1) / 2 like the reference
+                             (TSAR_FLAG_FIX_INIT_RADIUS); a context holding the reference view alone takes any box. */
     int32_t box_vsize;
     int32_t n_best;       /* --n_best (scripts 1; default 2) */
     int32_t cost_comb;    /* --cost_comb: TSAR_COMB_* */
@@ -223,8 +226,9 @@ int tsar_set_regions(tsar_ctx* ctx, const int32_t* labels, int n_regions, const 
                      const float* region_size, int mem);
 /* Weak-texture region detection of the reference view on the GPU (reference texture(), main.cpp:365-596):
  * computes lines->canny / cannylines->text / size and installs them like tsar_set_regions.  labels_out
- * [h][w] int32, text_out/size_out [cap] may be NULL.  The HoughLinesP boundary closing of the reference
- * (OpenCV-internal) is not reproduced. */
+ * [h][w] int32, text_out/size_out [cap] may be NULL.  The boundary closing of large regions (main.cpp:385-435) runs a
+ * deterministic Hough transform with the reference's parameters in place of OpenCV's randomised HoughLinesP, whose
+ * arithmetic is not in the reference's sources (parity unpinned for that step; TSAR_FLAG_NO_LINE_CLOSING skips it). */
 int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int mem, int* n_regions_out, float* text_out,
                              float* size_out, int cap);
 /* GPU replacement of the per-region CPU RANSAC; region_planes_out [n_regions][4] may be NULL */

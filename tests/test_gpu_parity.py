@@ -473,8 +473,25 @@ def test_error_codes(small_scene):
     with pytest.raises(api.TsarError) as e:
         m.set_views([im + 0.25 for im in sc.images], sc.K, sc.R, sc.t)
     assert e.value.code == api.TSAR_ERR_INVALID
+    assert "not 8-bit" in str(e.value)
     m.set_params(api.default_params(box_hsize=23, box_vsize=23, depth_min=sc.depth_min, depth_max=sc.depth_max))
     m.set_views([im + 0.25 for im in sc.images], sc.K, sc.R, sc.t)   # the largest square box of the float path
+    # box 24 on float imagery: the sweeps' window (radius 11) fits, gipuma_init_cu2's own (radius 12, gipuma.cu:693-694) does not
+    m.set_params(api.default_params(box_hsize=24, box_vsize=24, depth_min=sc.depth_min, depth_max=sc.depth_max))
+    with pytest.raises(api.TsarError) as e:
+        m.set_views([im + 0.25 for im in sc.images], sc.K, sc.R, sc.t)
+    assert e.value.code == api.TSAR_ERR_INVALID
+    m.set_params(api.default_params(box_hsize=24, box_vsize=24, depth_min=sc.depth_min, depth_max=sc.depth_max, flags=api.FLAG_FIX_INIT_RADIUS))
+    m.set_views([im + 0.25 for im in sc.images], sc.K, sc.R, sc.t)
+    m.close()
+    # 8-bit imagery, a rectangular box whose radii have mixed parity: 63 x 61 has 202 distinct tap distances, more than the shared
+    # weight table holds — refused with that reason; the same box on the reference view alone (refinement operators only) is fine
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=63, box_vsize=61, depth_min=sc.depth_min, depth_max=sc.depth_max))
+    with pytest.raises(api.TsarError) as e:
+        m.set_views(sc.images, sc.K, sc.R, sc.t)
+    assert e.value.code == api.TSAR_ERR_INVALID and "distinct tap distances" in str(e.value)
+    m.set_views(sc.images[:1], sc.K[:1], sc.R[:1], sc.t[:1])
     m.close()
     m = api.matcher_from_scene(sc)
     with pytest.raises(api.TsarError) as e:

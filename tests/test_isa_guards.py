@@ -1,0 +1,58 @@
+"""Build-time guard for the hand-issued gathers of the tap loops (tools/check_asm_gathers.py): no instruction may touch the
+destination register of a `buffer_load_dword ... idxen` between the load and the s_waitcnt that retires it — the compiler cannot
+know those registers are in flight, because the loads and their waits are inline asm.  Runs without a GPU: hipcc cross-compiles
+the two translation units that contain such gathers and the checker walks every kernel's control-flow graph."""
+import importlib.util
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_asm_gathers", os.path.join(ROOT, "tools", "check_asm_gathers.py"))
+chk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(chk)
+
+KERNEL = """_Z1kv: ; @_Z1kv
+	s_load_dwordx4 s[8:11], s[0:1], 0x0
+	buffer_load_dword v10, v1, s[8:11], 0 idxen
+	buffer_load_dword v11, v2, s[8:11], 0 idxen
+	s_cbranch_scc1 .LBB0_2
+.LBB0_1:
+	v_add_f32_e32 v3, v4, v5
+	s_branch .LBB0_3
+.LBB0_2:
+	%s
+.LBB0_3:
+	s_waitcnt vmcnt(1)
+	v_cvt_f32_ubyte0 v6, v10
+	%s
+	s_waitcnt vmcnt(0)
+	v_cvt_f32_ubyte0 v7, v11
+	s_endpgm
+	.size	_Z1kv, .Lfunc_end0-_Z1kv
+"""
+
+
+@pytest.mark.parametrize("in_branch,after_first_wait,violations", [
+    ("v_mov_b32_e32 v8, v9", "v_mov_b32_e32 v8, v9", 0),
+    ("v_mov_b32_e32 v10, v9", "v_mov_b32_e32 v8, v9", 1),          # a write to an in-flight destination on one branch only
+    ("v_mov_b32_e32 v8, v9", "v_add_f32_e32 v8, v11, v9", 1),      # the second gather read after a wait that only retires the first
+    ("v_mov_b32_e32 v8, v[10:11]", "v_mov_b32_e32 v8, v9", 2),     # a register range that covers both
+])
+def test_checker_on_synthetic_kernels(tmp_path, in_branch, after_first_wait, violations):
+    p = tmp_path / "k.s"
+    p.write_text(KERNEL % (in_branch, after_first_wait))
+    bad, n = chk.check(str(p))
+    assert n == 2 and len(bad) == violations, bad
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+@pytest.mark.parametrize("unit", ["pm_sweep.hip", "pm_sweep_lut.hip"])
+def test_no_instruction_touches_a_gather_in_flight(tmp_path, unit):
+    out = tmp_path / (unit + ".s")
+    subprocess.run([os.path.join(ROOT, "tools", "isa.sh"), os.path.join(ROOT, "tsar-mvs_amd", "csrc", unit), str(out)], check=True, capture_output=True, timeout=900)
+    bad, n = chk.check(str(out))
+    assert n >= 36, "the translation unit no longer contains the asm-issued gathers this test guards"
+    assert not bad, "\n".join(bad[:10])

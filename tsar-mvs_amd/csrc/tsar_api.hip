@@ -379,15 +379,25 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     if (!sc.use_quad)
         for (auto& q : ctx->quad) dev_free(q);              // (float imagery: the textures are not used; re-allocated if a later call needs them)
     derive_cameras(ctx, cams);
+    // Can the matching kernels run this window?  8-bit imagery shares one weight table per workgroup (pm_core_lut.h): any box whose
+    // taps have <= TSAR_LUT_MAX_CLASSES distinct distances (every square box; rectangular ones unless their radii have mixed
+    // parity, e.g. 63 x 61 -> 202).  Everything else keeps the hoisted bilateral weights per thread in LDS, (hrad+1)(vrad+1) taps
+    // x 256 threads x 4 B beside the reference window, which bounds the box at 23.  Checked for the sweeps' window and, for even
+    // boxes, gipuma_init_cu2's own (init_window_differs); a context with the reference view alone never matches (refinement
+    // operators only) and takes any box.
+    auto window_problem = [&](bool for_init) -> const char* {
+        fill_scene_params(ctx, for_init);
+        if (lut_path_applies(ctx)) return nullptr;
+        const size_t lds = (size_t)(sc.hrad + 1) * (sc.vrad + 1) * 1024 + (size_t)(32 + 2 * sc.hrad) * (16 + 2 * sc.vrad) * 4 + 16;
+        if (lds <= 160 * 1024) return nullptr;
+        if (!sc.use_quad) return "box too large for images that are not 8-bit: the per-thread weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)";
+        if (sc.lut_classes == 0) return "this rectangular box has more than 144 distinct tap distances (radii of mixed parity): the shared weight table cannot hold them and the per-thread table does not fit LDS; use radii of equal parity, or a box of at most 23";
+        return "box too large for fast mode on this device: the D16 LDS-load probe failed, so the general-window loop is not available; use TSAR_FLAG_STRICT_DIV, or a box of at most 23";
+    };
+    const char* problem = n_views > 1 ? window_problem(false) : nullptr;
+    if (!problem && n_views > 1 && init_window_differs(ctx)) problem = window_problem(true);
     fill_scene_params(ctx);
-    if (!lut_path_applies(ctx)) {
-        // float imagery keeps the hoisted bilateral weights per thread in LDS, (hrad+1)(vrad+1) taps x
-        // 256 threads x 4 B beside the reference window; 8-bit imagery shares one table per workgroup (pm_core_lut.h): any box
-        const int hr_ = init_window_differs(ctx) ? ctx->params.box_hsize / 2 : sc.hrad, vr_ = init_window_differs(ctx) ? ctx->params.box_vsize / 2 : sc.vrad;   // the larger of the two windows
-        const size_t lds = (size_t)(hr_ + 1) * (vr_ + 1) * 1024 + (size_t)(32 + 2 * hr_) * (16 + 2 * vr_) * 4 + 16;
-        if (lds > 160 * 1024)
-            return fail(ctx, TSAR_ERR_INVALID, "box too large for images that are not 8-bit: the per-thread weight table does not fit the 160 KiB of LDS per CU (largest square box: 23)");
-    }
+    if (problem) return fail(ctx, TSAR_ERR_INVALID, problem);
     sc.n_sel = std::min(n_views - 1, TSAR_MAX_SELECTED);   // default subset: the first 32 source views at most (tsar_set_view_subset picks others)
     for (int i = 0; i < sc.n_sel; i++) sc.sel[i] = i + 1;
     // state planes (LineState::resize linestate.h:71-110)

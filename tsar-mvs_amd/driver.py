@@ -35,6 +35,8 @@ def gather_results(dist, tensors: Sequence, dst: int = 0, out=None, async_op: bo
     import torch
     world = dist.get_world_size()
     rank = dist.get_rank()
+    if async_op and out is None and rank == dst:           # before anything is enqueued: temporaries would be dropped with the gather in flight
+        raise ValueError("async gather needs caller-owned receive buffers (alloc_gather_buffers)")
     res, works = [], []
     for k, t in enumerate(tensors):
         if rank == dst:
@@ -45,7 +47,5 @@ def gather_results(dist, tensors: Sequence, dst: int = 0, out=None, async_op: bo
             wk = dist.gather(t, None, dst=dst, async_op=async_op)
         works.append(wk)
     if async_op:
-        if out is None and rank == dst:
-            raise ValueError("async gather needs caller-owned receive buffers (alloc_gather_buffers)")
         return works
     return res if rank == dst else None

@@ -268,7 +268,8 @@ struct HostResult {
     PinnedFloats depth, normal;
     std::string out_dir;        // where the view's .dmb files go
     int w = 0, h = 0;
-    tsar_ctx** shared_ctx = nullptr;   // --all: the worker's context, kept across its views (device planes are allocated once)
+    tsar_ctx** shared_ctx = nullptr;   // the worker's context, kept across its views (device planes are allocated once)
+    bool device_image_cache = false;   // --all: images stay resident on the device across views (a one-view process would only hold every image twice)
 };
 static bool write_view_files(const HostResult& r) {   // the two files side by side: a write is a copy into the page cache
     auto normals = std::async(std::launch::async, [&r]() { return write_dmb(r.out_dir + "TSAR_normals.dmb", r.normal.data(), r.h, r.w, 3); });
@@ -331,7 +332,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         if (i == 0) { w = wi; h = hi; }
         if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); drop_ctx(); return -1; }
         ptrs[i] = gray[i]->gray.data();
-        if (reuse && reuse->shared_ctx) {                         // --all: resident device copy (falls back to the host buffer)
+        if (reuse && reuse->device_image_cache) {                 // --all: resident device copy (falls back to the host buffer)
             const float* d = g_device_images.get(device, ip, *gray[i]);
             if (d) dev_ptrs.push_back(d);
         }
@@ -470,6 +471,7 @@ int main(int argc, char** argv) {
                 HostResult host_result[2];
                 tsar_ctx* worker_ctx = nullptr;
                 host_result[0].shared_ctx = host_result[1].shared_ctx = &worker_ctx;
+                host_result[0].device_image_cache = host_result[1].device_image_cache = true;
                 std::future<bool> writing[2];
                 // refinement modes: a ring of (page-locked) input buffers; the maps, weak.png and reference image of the next seven
                 // views are read while view k is on the GPU (one weak.png inflates in ~0.3 s, a view's kernels take ~0.1 s)
@@ -516,6 +518,7 @@ int main(int argc, char** argv) {
         if (o.fuse) {
             // gather: every view's maps to GPU 0 (peer copies over xGMI; views matched on GPU 0 are already there), then fuse
             const auto t0 = std::chrono::steady_clock::now();
+            if (refs.empty() || kept.empty()) { fprintf(stderr, "--fuse: no view was matched\n"); return 1; }
             const int n = (int)refs.size(), fw = kept[0].w, fh = kept[0].h;
             const size_t np = (size_t)fw * fh;
             std::map<int, int> slot;
@@ -531,6 +534,8 @@ int main(int argc, char** argv) {
                 if (kept[k].device != 0) {
                     float* d0 = (float*)tsar_device_alloc(0, np * 4);
                     float* n0 = (float*)tsar_device_alloc(0, np * 12);
+                    if (d0) owned.push_back(d0);            // released on every error path below
+                    if (n0) owned.push_back(n0);
                     if (!d0 || !n0 || tsar_peer_copy(0, d0, kept[k].device, d, np * 4) != TSAR_OK || tsar_peer_copy(0, n0, kept[k].device, nr, np * 12) != TSAR_OK) {
                         fprintf(stderr, "--fuse: gather of view %08d from gpu %d failed\n", refs[k], kept[k].device);
                         release();
@@ -540,8 +545,9 @@ int main(int argc, char** argv) {
                     tsar_device_free(kept[k].device, nr);
                     d = d0; nr = n0;
                     moved += np * 16;
+                } else {
+                    owned.push_back(d); owned.push_back(nr);
                 }
-                owned.push_back(d); owned.push_back(nr);
                 char buf[32];
                 snprintf(buf, sizeof buf, "%08d.pgm", refs[k]);
                 auto img = g_images.get(o.images_folder + pnm_name(buf, o.color ? ".ppm" : ".pgm"));
