@@ -541,7 +541,14 @@ int orc_refine_steps(const orc_state *s) {
  * final_text != NULL is the kernels' `final == true` mode: pixels whose lines->text is -1 are left
  * untouched (gipuma.cu:856, :1063) and accepted hypotheses do not write ratio / beview
  * (gipuma.cu:559-562, :669-672). */
+static void pm_sweep_impl_rects(orc_state *s, int colour, int do_prop, int do_refine, const float *final_text, int n_rects, const int32_t *rects);
 static void pm_sweep_impl(orc_state *s, int colour, int do_prop, int do_refine, const float *final_text) {
+    pm_sweep_impl_rects(s, colour, do_prop, do_refine, final_text, 0, NULL);
+}
+/* n_rects > 0: only the pixels inside one of the rectangles rects[4 k .. 4 k + 3] = (x0, y0, x1, y1), x1 / y1 exclusive, are
+ * updated (every read still sees the launch-start state of the whole image): what lets a test check a full-size launch of the
+ * GPU path on windows of it in seconds instead of minutes. */
+static void pm_sweep_impl_rects(orc_state *s, int colour, int do_prop, int do_refine, const float *final_text, int n_rects, const int32_t *rects) {
     const size_t np = (size_t)s->w * s->h;
     float *c_snap = (float *)malloc(np * sizeof(float));
     float *n_snap = (float *)malloc(np * 4 * sizeof(float));
@@ -552,6 +559,12 @@ static void pm_sweep_impl(orc_state *s, int colour, int do_prop, int do_refine, 
     for (int y = 0; y < s->h; y++)
         for (int x = 0; x < s->w; x++) {
             if (((x + y) & 1) != colour) continue;
+            if (n_rects > 0) {
+                int inside = 0;
+                for (int k = 0; k < n_rects && !inside; k++)
+                    inside = x >= rects[4 * k] && y >= rects[4 * k + 1] && x < rects[4 * k + 2] && y < rects[4 * k + 3];
+                if (!inside) continue;
+            }
             size_t p = (size_t)y * s->w + x;
             if (final_text && final_text[p] == -1.0f) continue;
             pix_t px;
@@ -567,6 +580,9 @@ static void pm_sweep_impl(orc_state *s, int colour, int do_prop, int do_refine, 
     s->launch++;
 }
 void orc_pm_sweep(orc_state *s, int colour, int do_prop, int do_refine) { pm_sweep_impl(s, colour, do_prop, do_refine, NULL); }
+void orc_pm_sweep_rects(orc_state *s, int colour, int do_prop, int do_refine, int n_rects, const int32_t *rects) {
+    pm_sweep_impl_rects(s, colour, do_prop, do_refine, NULL, n_rects, rects);
+}
 /* host loop of gipuma_first gipuma.cu:1744-1754 */
 void orc_pm_iterate(orc_state *s, int iters) {
     for (int it = 0; it < iters; it++) {

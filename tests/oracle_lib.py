@@ -64,7 +64,7 @@ def lib():
         L.orc_set_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
         L.orc_derive_cameras.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.orc_rng4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
-        for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_iterate", "orc_pm_iterate_final", "orc_pm_cost_planes",
+        for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_sweep_rects", "orc_pm_iterate", "orc_pm_iterate_final", "orc_pm_cost_planes",
                   "orc_select_candidates", "orc_homography", "orc_view_vector", "orc_load_planes", "orc_compute_disp",
                   "orc_depth_to_plane", "orc_compute_disp_final", "orc_lrdiff", "orc_getview", "orc_fake_depth",
                   "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch", "orc_wmf_detect", "orc_wmf_fill",
@@ -232,6 +232,11 @@ class Oracle:
 
     def pm_sweep(self, colour, do_prop=1, do_refine=1):
         self.L.orc_pm_sweep(self.s, C.c_int(colour), C.c_int(do_prop), C.c_int(do_refine))
+
+    def pm_sweep_rects(self, colour, rects, do_prop=1, do_refine=1):
+        """the same launch restricted to the pixels inside the rectangles [(x0, y0, x1, y1), ...] (reads see the whole image)"""
+        r = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+        self.L.orc_pm_sweep_rects(self.s, C.c_int(colour), C.c_int(do_prop), C.c_int(do_refine), C.c_int(len(r)), _p(r))
 
     def pm_iterate(self, iters):
         self.L.orc_pm_iterate(self.s, C.c_int(iters))

@@ -397,3 +397,49 @@ def test_bench_workload_full_size_first_steps_bit_exact():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rep = json.loads(out.stdout)
     assert rep["all_bit_identical"] is True and rep["steps"][0]["after"] == "pm_init" and rep["steps"][0]["pixels"] == 6048 * 4032
+
+
+def test_bench_workload_full_size_every_half_sweep_on_windows():
+    """BASELINE configs[1] at its full size (6048x4032, 1 + 10 views, 8 iterations), strict mode: EVERY one of the 16 half-sweeps
+    of the run the bench times is checked against the oracle, bit for bit, on twelve 192 x 160 windows of the image (corners,
+    borders, interior: 0.37 Mpixel).  Before each launch the oracle takes the GPU's state (so each launch is judged on its own
+    inputs: propagation reads up to 23 pixels beyond a window), runs the same launch restricted to the windows
+    (orc_pm_sweep_rects: ~0.6 s of 16 host cores instead of a minute for the whole image) and the planes and costs of the swept
+    colour inside the windows must match.  The whole-image version of this comparison is tools/full_size_oracle_check.py
+    (profiles/r02/full_size_oracle_check.json: five iterations, ~2 minutes of oracle time each)."""
+    import torch
+    W, H = 6048, 4032
+    sc = synth.make_scene(W, H, 10, device="cuda", seed=1234)
+    images = [im.cpu().numpy() for im in sc.images]
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=11, n_best=1)
+    m = api.matcher_from_scene(sc, box=11, n_best=1, seed=2024, flags=api.FLAG_STRICT_DIV)
+    rw, rh = 192, 160
+    xs, ys = [0, W // 3 - 7, 2 * W // 3 + 5, W - rw], [0, H // 2 - 3, H - rh]
+    rects = [(x, y, x + rw, y + rh) for y in ys for x in xs]
+    mask = np.zeros((H, W), bool)
+    for x0, y0, x1, y1 in rects:
+        mask[y0:y1, x0:x1] = True
+    yy, xx = np.nonzero(mask)
+    m.pm_init()
+    planes, cost, _, _ = m.get_plane()
+    changed = 0
+    for sweep in range(16):
+        colour = sweep & 1
+        orc.norm4[...] = planes
+        orc.c[...] = cost
+        orc.set_launch(sweep)
+        orc.pm_sweep_rects(colour, rects)
+        m.pm_sweep(colour)
+        planes_after, cost_after, _, _ = m.get_plane()
+        sel = ((xx + yy) & 1) == colour
+        py, px = yy[sel], xx[sel]
+        assert np.array_equal(cost_after[py, px], orc.c[py, px]), "costs differ after half-sweep %d" % sweep
+        assert np.array_equal(planes_after[py, px].view(np.uint32), orc.norm4[py, px].view(np.uint32)), "planes differ after half-sweep %d" % sweep
+        changed += int((cost_after[py, px] != cost[py, px]).sum())
+        planes, cost = planes_after, cost_after
+    assert changed > 100000                  # the sweeps did work inside the windows
+    gt = sc.gt_depth.cpu().numpy()
+    m.compute_disp()
+    depth = m.get_result(("depth",))["depth"]
+    assert (np.abs(depth - gt) / gt < 0.01).mean() > 0.99      # and the run converged (bench.py reports the same figure)
+    m.close()

@@ -13,6 +13,7 @@
 // Deterministic choices (the reference uses rand() and a time-seeded shuffle): raster-order point
 // lists, even subsampling to 49999 points above 50000, Philox draws keyed by (draw, stage, region).
 #include <chrono>
+#include <mutex>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
@@ -694,6 +695,13 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                 int coop = 0;
                 if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device) != hipSuccess) coop = 0;
                 if (getenv("TSAR_RANSAC_COOPERATIVE") && getenv("TSAR_RANSAC_COOPERATIVE")[0] == '0') coop = 0;
+                // One cooperative grid at a time per process: the contexts of one process (tsar_gipuma --workers=2, ranks' threads) would
+                // otherwise compete for the CUs their grids must hold together — and two threads inside hipLaunchCooperativeKernel at
+                // once leave the runtime (ROCm 7.2) in a state that crashes at process exit (seen in the two-contexts test).  The lock
+                // is held until the grid has drained.
+                static std::mutex coop_mutex;
+                std::unique_lock<std::mutex> coop_lock(coop_mutex, std::defer_lock);
+                if (coop) coop_lock.lock();
                 hipError_t le = coop ? hipLaunchCooperativeKernel(mw, dim3(nslot * wgs), dim3(RS_BLOCK), args, 0, st)
                                      : hipLaunchKernel(mw, dim3(nslot * wgs), dim3(RS_BLOCK), args, 0, st);
                 if (le == hipSuccess) {
@@ -704,6 +712,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                 } else {
                     (void)hipGetLastError();                  // the grid could not be placed as a whole (or no cooperative launches here): one workgroup per region below
                 }
+                if (coop) coop_lock.unlock();
                 if (trace) fprintf(stderr, "[ransac] stage 2 on %d workgroups per region: %s%s\n", wgs, coop ? "cooperative launch" : "plain launch", fitted ? "" : " -> fallback to one workgroup per region");
             }
             if (!fitted)
