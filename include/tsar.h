@@ -291,7 +291,8 @@ int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, int cap, int*
  * with one v_rcp_f32 + Newton step and one residual correction per quotient instead of the compiler's IEEE division sequence, behind
  * an operand guard that falls back to the latter.  These run that code path on caller-supplied or device-generated operands so a
  * test can compare it with IEEE division (the host's `/`, or the device's) bit for bit.
- *   tsar_selftest_divide: host arrays in / out; ieee != 0 returns the device's IEEE quotients instead.
+ *   tsar_selftest_divide: host arrays in / out; ieee = 1 returns the device's IEEE quotients instead, ieee = 2 the fast mode's
+ *   X * v_rcp_f32(Z) (with X = 1: the device's reciprocal itself, which the CPU oracle's restatement of the fast arithmetic reads).
  *   tsar_selftest_divide_random: 2^log2_triples (X, Y, Z) triples generated on the device (mode 0: like the tap loop's operands;
  *   1: any mantissa / sign, exponents across the guard range; 2: any bit pattern); guarded = 0 runs the form without the guard (the
  *   clamp-free tap loops; modes 0 and 1).  Returns the number of quotients that differ from `/` and of triples outside the guard. */

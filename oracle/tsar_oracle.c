@@ -44,12 +44,30 @@
 #define ORC_FLAG_FIX_RIGHT_FAR_CMP (1u << 1)
 #define ORC_FLAG_TEX_FILTER_8BIT (1u << 5)
 #define ORC_FLAG_FIX_INIT_RADIUS (1u << 6) /* gipuma_init_cu2 on the sweeps' window instead of its own box / 2 (gipuma.cu:693-694) */
+/* S7: the arithmetic of the HIP library's default ("fast") mode, restated so that the mode bench.py times can be checked bit for
+ * bit too, not only statistically.  It is the reference's algorithm with five ROUNDING liberties, none of which changes which
+ * operations are done on which data:
+ *   (1) the per-tap perspective divide is one reciprocal and two multiplies, u = X * rcp(Z), v = Y * rcp(Z), where rcp is the
+ *       GPU's v_rcp_f32 (1 ulp) — a hardware function, so the oracle evaluates it from a table of its 2^23 mantissa results that the
+ *       test reads from the device once (orc_set_rcp_table; the exponent is handled exactly);
+ *   (2) the plane homography as H = A - b m^T with A = K R K_ref^-1 and b = K t folded per view in double precision on the host,
+ *       m = K_ref^-T n * rcp(d);
+ *   (3) the cross sum accumulates (w s) r instead of (w r) s;
+ *   (4) positions are clamped to [0, w - 1] x [0, h - 1] instead of [-1, w] x [-1, h] — the same sample bit for bit (edge
+ *       replication), so the oracle's bilinear() serves both;
+ *   (5) ORC_FLAG_ROW_ORDER: the three source sums run over the window row by row (x fastest) instead of column by column
+ *       (what the 8-bit-imagery kernels do; float imagery keeps columns).
+ * The strict mode (no flag) remains the restatement of the reference; this mode is pinned to it only through the tolerances
+ * stated in tests/test_gpu_fast_mode.py. */
+#define ORC_FLAG_FAST_ARITH (1u << 7)
+#define ORC_FLAG_ROW_ORDER (1u << 8)
 
 typedef struct {
     float K[9], Kinv[9], R[9], t[3]; /* pose relative to the reference camera (ref = K[I|0]) */
     float Minv[9], P34[3], C[3];     /* of P = K_ref [R|t] (cameraGeometryUtils.h:302-356) */
     float Rorig[9], RorigInv[9];
     float fx, fy, f, alpha, baseline, depthMin, depthMax;
+    float A[9], b[3];                /* S7 (2): K R K_ref^-1 and K t */
 } orc_camera;
 
 typedef struct {
@@ -69,6 +87,8 @@ typedef struct {
     int n_regions;
     float *region_text, *region_norm4, *region_size;
     int launch; /* number of red/black launches so far (RNG stream) */
+    const float *rcp_table; /* S7 (1): v_rcp_f32 of 1 + m 2^-23 for m = 0 .. 2^23 - 1, borrowed */
+    int rcp_out_of_range;   /* S7 (1): operands the table could not serve (zero, denormal, inf, nan, result not normal): must stay 0 */
 } orc_state;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -215,6 +235,18 @@ void orc_derive_cameras(orc_state *s, int n_views, const float *K, const float *
             cm->P34[r] = (float)P34[r];
             cm->C[r] = (float)(-(Rrel[r] * trel[0] + Rrel[3 + r] * trel[1] + Rrel[6 + r] * trel[2]));
         }
+        {   /* S7 (2): A = K R K_ref^-1, b = K t, in the library's own expression order (cofactors first, det along the first row) */
+            double Ki[9], KR[9], A[9];
+            const double c00 = K0[4] * K0[8] - K0[5] * K0[7], c01 = K0[5] * K0[6] - K0[3] * K0[8], c02 = K0[3] * K0[7] - K0[4] * K0[6];
+            const double sdet = 1.0 / (K0[0] * c00 + K0[1] * c01 + K0[2] * c02);
+            Ki[0] = c00 * sdet; Ki[1] = (K0[2] * K0[7] - K0[1] * K0[8]) * sdet; Ki[2] = (K0[1] * K0[5] - K0[2] * K0[4]) * sdet;
+            Ki[3] = c01 * sdet; Ki[4] = (K0[0] * K0[8] - K0[2] * K0[6]) * sdet; Ki[5] = (K0[2] * K0[3] - K0[0] * K0[5]) * sdet;
+            Ki[6] = c02 * sdet; Ki[7] = (K0[1] * K0[6] - K0[0] * K0[7]) * sdet; Ki[8] = (K0[0] * K0[4] - K0[1] * K0[3]) * sdet;
+            mul3d(Kv, Rrel, KR);
+            mul3d(KR, Ki, A);
+            for (int i = 0; i < 9; i++) cm->A[i] = (float)A[i];
+            for (int r = 0; r < 3; r++) cm->b[r] = (float)(Kv[r * 3] * trel[0] + Kv[r * 3 + 1] * trel[1] + Kv[r * 3 + 2] * trel[2]);
+        }
         cm->fx = (float)K0[0]; cm->fy = (float)K0[4]; cm->f = (float)K0[0];
         cm->alpha = (float)K0[0] / (float)K0[4];
         cm->baseline = 1.0f; /* cameraGeometryUtils.h:309 */
@@ -268,9 +300,78 @@ static inline void homography(const orc_camera *ref, const orc_camera *to, const
 }
 void orc_homography(const orc_state *s, int view, const float *n4, float *H) { homography(&s->cam[0], &s->cam[view], n4, H); }
 
+/* S7 (1): v_rcp_f32 from the device's mantissa table; the exponent and sign are exact */
+static inline float rcp_gpu(const orc_state *s, float x) {
+    union { float f; uint32_t u; } a, r;
+    a.f = x;
+    const uint32_t e = (a.u >> 23) & 0xffu, m = a.u & 0x7fffffu;
+    if (!s->rcp_table || e == 0 || e == 255) { ((orc_state *)s)->rcp_out_of_range = 1; return 1.0f / x; }
+    r.f = s->rcp_table[m];                       /* in (0.5, 1]: exponent field 126, or 127 for m = 0 */
+    const int re = (int)((r.u >> 23) & 0xffu) + 127 - (int)e;
+    if (re <= 0 || re >= 255) { ((orc_state *)s)->rcp_out_of_range = 1; return 1.0f / x; }
+    r.u = (a.u & 0x80000000u) | ((uint32_t)re << 23) | (r.u & 0x7fffffu);
+    return r.f;
+}
+/* S7 (2): plane_homography_fast of the HIP library (tsar_device_math.h) */
+static inline void homography_fast(const orc_state *s, const orc_camera *ref, const orc_camera *to, const float *n4, float *H) {
+    const float inv_d = rcp_gpu(s, n4[3]);
+    float m[3];
+    for (int c = 0; c < 3; c++) m[c] = fmaf(n4[2], ref->Kinv[6 + c], fmaf(n4[1], ref->Kinv[3 + c], n4[0] * ref->Kinv[c])) * inv_d;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) H[r * 3 + c] = fmaf(-to->b[r], m[c], to->A[r * 3 + c]);
+}
+/* pmCost in the fast arithmetic (S7).  The reference terms (weights, sum w, sum w r, sum w r^2) are the strict ones in the strict
+ * order — the kernels hoist them per pixel in both modes; only the three source sums follow the liberties. */
+static float pm_cost_fast(const orc_state *s, int view, int x, int y, const float *n4) {
+    const float *l = s->img[0], *r = s->img[view];
+    const int w = s->w, h = s->h;
+    const int q8 = (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0, rows = (s->flags & ORC_FLAG_ROW_ORDER) != 0;
+    float H[9];
+    homography_fast(s, &s->cam[0], &s->cam[view], n4, H);
+    const float cen = texel(l, w, h, x, y);
+    float sum_ref = 0, sum_ref_ref = 0, wsum = 0;
+    for (int i = -s->hrad; i < s->hrad + 1; i += 2)
+        for (int j = -s->vrad; j < s->vrad + 1; j += 2) {
+            const float ref_pix = texel(l, w, h, x + i, y + j);
+            const float wt = orc_expf(-sqrtf((float)(i * i + j * j)) / 50.0f - fabsf(ref_pix - cen) / 18.0f);
+            const float wr = wt * ref_pix;
+            sum_ref += wr;
+            sum_ref_ref = fmaf(wr, ref_pix, sum_ref_ref);
+            wsum += wt;
+        }
+    float sum_src = 0, sum_src_src = 0, sum_ref_src = 0;
+    const int ro = rows ? s->vrad : s->hrad, ri = rows ? s->hrad : s->vrad;      /* radius of the outer / inner loop */
+    for (int a = -ro; a < ro + 1; a += 2) {
+        const float fa = (float)((rows ? y : x) + a);
+        const float bx = fmaf(H[rows ? 1 : 0], fa, H[2]), by = fmaf(H[rows ? 4 : 3], fa, H[5]), bz = fmaf(H[rows ? 7 : 6], fa, H[8]);
+        for (int b = -ri; b < ri + 1; b += 2) {
+            const float fb = (float)((rows ? x : y) + b);
+            const float X = fmaf(H[rows ? 0 : 1], fb, bx), Y = fmaf(H[rows ? 3 : 4], fb, by), Z = fmaf(H[rows ? 6 : 7], fb, bz);
+            const int i = rows ? b : a, j = rows ? a : b;                      /* x and y offset of this tap */
+            const float ref_pix = texel(l, w, h, x + i, y + j);
+            const float wt = orc_expf(-sqrtf((float)(i * i + j * j)) / 50.0f - fabsf(ref_pix - cen) / 18.0f);
+            const float rz = rcp_gpu(s, Z);
+            const float src_pix = bilinear_q(r, w, h, X * rz, Y * rz, q8);
+            const float ws = wt * src_pix;
+            sum_src += ws;
+            sum_src_src = fmaf(ws, src_pix, sum_src_src);
+            sum_ref_src = fmaf(ws, ref_pix, sum_ref_src);
+        }
+    }
+    const float inv = 1.0f / wsum;
+    sum_ref *= inv; sum_ref_ref *= inv; sum_src *= inv; sum_src_src *= inv; sum_ref_src *= inv;
+    const float var_ref = sum_ref_ref - sum_ref * sum_ref;
+    const float var_src = sum_src_src - sum_src * sum_src;
+    if (var_ref < 1e-5f || var_src < 1e-5f) return ORC_MAXCOST;
+    const float covar = sum_ref_src - sum_ref * sum_src;
+    const float vrs = sqrtf(var_ref * var_src);
+    return fmaxf(0.0f, fminf(ORC_MAXCOST, 1.0f - covar / vrs));
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* pmCost gipuma.cu:229-298: bilateral-weighted NCC over the dilated window                     */
 static float pm_cost(const orc_state *s, int view, int x, int y, const float *n4) {
+    if (s->flags & ORC_FLAG_FAST_ARITH) return pm_cost_fast(s, view, x, y, n4);
     const float *l = s->img[0], *r = s->img[view];
     const int w = s->w, h = s->h;
     float H[9];
@@ -701,7 +802,9 @@ static float rl_cost(const orc_state *s, int view, int x, int y, const float *n4
             float qx = (float)plx, qy = (float)ply;
             float Z = fmaf(V[7], qy, fmaf(V[6], qx, V[8]));
             float X = fmaf(V[1], qy, fmaf(V[0], qx, V[2])), Y = fmaf(V[4], qy, fmaf(V[3], qx, V[5]));
-            float src_pix = bilinear_q(l, w, h, X / Z, Y / Z, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
+            float u_ = X / Z, v_ = Y / Z;
+            if (s->flags & ORC_FLAG_FAST_ARITH) { const float rz = rcp_gpu(s, Z); u_ = X * rz; v_ = Y * rz; }   /* S7 (1): the one liberty lrdiff takes */
+            float src_pix = bilinear_q(l, w, h, u_, v_, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
             float sd = sqrtf((float)(i * i + j * j));
             float cd = fabsf(ref_pix - cen);
             float wt = orc_expf(-sd / 50.0f - cd / 18.0f);
@@ -813,6 +916,9 @@ void orc_set_params(orc_state *s, int box_hsize, int box_vsize, int n_best, int 
     s->box_hsize = box_hsize; s->box_vsize = box_vsize;
     s->n_best = n_best; s->cost_comb = cost_comb; s->flags = flags; s->seed = seed;
 }
+void orc_set_rcp_table(orc_state *s, const float *table) { s->rcp_table = table; s->rcp_out_of_range = 0; } /* S7 (1); borrowed */
+int orc_rcp_out_of_range(const orc_state *s) { return s->rcp_out_of_range; }
+float orc_rcp_gpu(const orc_state *s, float x) { return rcp_gpu(s, x); }
 void orc_set_subset(orc_state *s, int n, const int32_t *idx) {
     s->n_sel = n;
     for (int i = 0; i < n; i++) s->sel[i] = idx[i];

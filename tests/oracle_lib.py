@@ -79,6 +79,12 @@ def lib():
         L.orc_slic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_refine_steps.restype = C.c_int
         L.orc_refine_steps.argtypes = [C.c_void_p]
+        L.orc_set_rcp_table.restype = None
+        L.orc_set_rcp_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_rcp_out_of_range.restype = C.c_int
+        L.orc_rcp_out_of_range.argtypes = [C.c_void_p]
+        L.orc_rcp_gpu.restype = C.c_float
+        L.orc_rcp_gpu.argtypes = [C.c_void_p, C.c_float]
         _lib = L
     return _lib
 
@@ -92,7 +98,13 @@ class CameraView(C.Structure):
                 ("Minv", C.c_float * 9), ("P34", C.c_float * 3), ("C", C.c_float * 3),
                 ("Rorig", C.c_float * 9), ("RorigInv", C.c_float * 9),
                 ("fx", C.c_float), ("fy", C.c_float), ("f", C.c_float), ("alpha", C.c_float),
-                ("baseline", C.c_float), ("depthMin", C.c_float), ("depthMax", C.c_float)]
+                ("baseline", C.c_float), ("depthMin", C.c_float), ("depthMax", C.c_float),
+                ("A", C.c_float * 9), ("b", C.c_float * 3)]
+
+
+# oracle/tsar_oracle.c S7: the arithmetic of the HIP library's default mode (needs the device's v_rcp_f32 table, set_rcp_table)
+FLAG_FAST_ARITH, FLAG_ROW_ORDER = 128, 256
+FLAGS_FAST_8BIT_IMAGERY = FLAG_FAST_ARITH | FLAG_ROW_ORDER      # what the production kernels for 8-bit imagery compute
 
 
 class Oracle:
@@ -226,6 +238,17 @@ class Oracle:
         sub = np.asarray(subset, dtype=np.int32)
         self.L.orc_set_subset(self.s, len(sub), _p(sub))
         self.n_sel = len(sub)
+
+    def set_rcp_table(self, table):
+        """the device's v_rcp_f32 results for the 2^23 mantissas of [1, 2) (rcp_table_from_device): needed by FLAG_FAST_ARITH"""
+        table = np.ascontiguousarray(table, np.float32)
+        assert table.size == 1 << 23
+        self._rcp_table = table              # borrowed by the C side
+        self.L.orc_set_rcp_table(self.s, _p(table))
+
+    @property
+    def rcp_out_of_range(self):
+        return bool(self.L.orc_rcp_out_of_range(self.s))
 
     def pm_init(self):
         self.L.orc_pm_init(self.s)
@@ -410,3 +433,17 @@ def fuse(depths, normals, grays, K, R, t, pairs, num_consistent=1, reproj_error=
     cnt = L.orc_fuse(n, w, h, cams, mk(d), mk(nr), mk(g), _p(off), _p(idx), num_consistent, C.c_float(reproj_error), C.c_float(depth_diff),
                      C.c_float(cos_angle), used_list, _p(out), cap)
     return out[:cnt].copy()
+
+
+_rcp_table_cache = {}
+
+
+def rcp_table_from_device(matcher):
+    """v_rcp_f32 of every fp32 in [1, 2), read from the GPU through the C ABI's self-test entry (fast form: u = X * rcp(Z) with
+    X = 1).  2^23 results, 32 MB; cached per process."""
+    if "t" not in _rcp_table_cache:
+        z = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+        one = np.ones_like(z)
+        u, _ = matcher.selftest_divide(one, one, z, mode=2)
+        _rcp_table_cache["t"] = u
+    return _rcp_table_cache["t"]

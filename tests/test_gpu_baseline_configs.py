@@ -399,8 +399,11 @@ def test_bench_workload_full_size_first_steps_bit_exact():
     assert rep["all_bit_identical"] is True and rep["steps"][0]["after"] == "pm_init" and rep["steps"][0]["pixels"] == 6048 * 4032
 
 
-def test_bench_workload_full_size_every_half_sweep_on_windows():
-    """BASELINE configs[1] at its full size (6048x4032, 1 + 10 views, 8 iterations), strict mode: EVERY one of the 16 half-sweeps
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_bench_workload_full_size_every_half_sweep_on_windows(mode):
+    """BASELINE configs[1] at its full size (6048x4032, 1 + 10 views, 8 iterations), in the arithmetic bench.py times ("fast":
+    against the oracle's restatement of that arithmetic, oracle/tsar_oracle.c S7, with the device's v_rcp_f32 table) and in the
+    reference's arithmetic ("strict"): EVERY one of the 16 half-sweeps
     of the run the bench times is checked against the oracle, bit for bit, on twelve 192 x 160 windows of the image (corners,
     borders, interior: 0.37 Mpixel).  Before each launch the oracle takes the GPU's state (so each launch is judged on its own
     inputs: propagation reads up to 23 pixels beyond a window), runs the same launch restricted to the windows
@@ -411,8 +414,10 @@ def test_bench_workload_full_size_every_half_sweep_on_windows():
     W, H = 6048, 4032
     sc = synth.make_scene(W, H, 10, device="cuda", seed=1234)
     images = [im.cpu().numpy() for im in sc.images]
-    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=11, n_best=1)
-    m = api.matcher_from_scene(sc, box=11, n_best=1, seed=2024, flags=api.FLAG_STRICT_DIV)
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=11, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY if mode == "fast" else 0)
+    m = api.matcher_from_scene(sc, box=11, n_best=1, seed=2024, flags=0 if mode == "fast" else api.FLAG_STRICT_DIV)
+    if mode == "fast":
+        orc.set_rcp_table(ol.rcp_table_from_device(m))
     rw, rh = 192, 160
     xs, ys = [0, W // 3 - 7, 2 * W // 3 + 5, W - rw], [0, H // 2 - 3, H - rh]
     rects = [(x, y, x + rw, y + rh) for y in ys for x in xs]
@@ -442,4 +447,5 @@ def test_bench_workload_full_size_every_half_sweep_on_windows():
     m.compute_disp()
     depth = m.get_result(("depth",))["depth"]
     assert (np.abs(depth - gt) / gt < 0.01).mean() > 0.99      # and the run converged (bench.py reports the same figure)
+    assert not orc.rcp_out_of_range
     m.close()

@@ -334,12 +334,13 @@ class Matcher:
         self._chk(self.L.tsar_lrdiff(self._ctx))
 
     # ---- self-tests ----
-    def selftest_divide(self, X, Y, Z, ieee: bool = False):
-        """(u, v) = (X / Z, Y / Z) as strict mode's tap loops compute them (ieee: as the device's IEEE division does)."""
+    def selftest_divide(self, X, Y, Z, ieee: bool = False, mode: int | None = None):
+        """(u, v) = (X / Z, Y / Z) as strict mode's tap loops compute them (mode 0); as the device's IEEE division does (ieee /
+        mode 1); as the fast mode computes them, X * v_rcp_f32(Z) (mode 2)."""
         X, Y, Z = (np.ascontiguousarray(a, dtype=np.float32) for a in (X, Y, Z))
         assert X.shape == Y.shape == Z.shape
         u, v = np.empty_like(X), np.empty_like(X)
-        self._chk(self.L.tsar_selftest_divide(self._ctx, _ptr(X)[0], _ptr(Y)[0], _ptr(Z)[0], X.size, _ptr(u)[0], _ptr(v)[0], int(ieee)))
+        self._chk(self.L.tsar_selftest_divide(self._ctx, _ptr(X)[0], _ptr(Y)[0], _ptr(Z)[0], X.size, _ptr(u)[0], _ptr(v)[0], int(ieee) if mode is None else mode))
         return u, v
 
     def selftest_sweep_census(self, colour: int) -> dict:

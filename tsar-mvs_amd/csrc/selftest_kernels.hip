@@ -11,7 +11,8 @@ __global__ __launch_bounds__(ST_BLOCK) void divide_arrays_kernel(const float* __
     const size_t i = (size_t)blockIdx.x * ST_BLOCK + threadIdx.x;
     if (i >= n) return;
     float a, b;
-    if (ieee) { a = X[i] / Z[i]; b = Y[i] / Z[i]; }
+    if (ieee == 2) { const float rz = __builtin_amdgcn_rcpf(Z[i]); a = X[i] * rz; b = Y[i] * rz; }      // the fast mode's form (pm_tap_r5.h)
+    else if (ieee) { a = X[i] / Z[i]; b = Y[i] / Z[i]; }
     else persp_divide_exact<true>(X[i], Y[i], Z[i], a, b);
     u[i] = a;
     v[i] = b;
