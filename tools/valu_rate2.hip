@@ -50,6 +50,12 @@ KERNEL(mul_hi, "v_mul_hi_u32 %0, %0, %1")
 KERNEL(rcp, "v_rcp_f32 %0, %0")
 KERNEL(sqrt, "v_sqrt_f32 %0, %0")
 KERNEL(exp, "v_exp_f32 %0, %0")
+// round 3: could the four byte converts of a tap be folded into mixed-precision FMAs on a half-float texture?
+KERNEL(fma_mix_lo, "v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[0,1,0]")                 // src1 read as f16 from the low half
+KERNEL(fma_mix_hi, "v_fma_mix_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]")  // ... from the high half
+KERNEL(fma_mix_2h, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,0]")  // two f16 operands
+KERNEL(cvt_f32_f16, "v_cvt_f32_f16 %0, %0")
+KERNEL(perm, "v_perm_b32 %0, %0, %1, %2")
 
 typedef void (*kfn)(float*, float, int);
 static double base_ns = 0;
@@ -77,5 +83,6 @@ int main() {
     RUN(fma); RUN(fma); RUN(mul); RUN(add); RUN(sub); RUN(max); RUN(med3); RUN(fract); RUN(floor); RUN(cvt_flr); RUN(cvt_ub0); RUN(cvt_ub1);
     RUN(cvt_f32_i32); RUN(cvt_i32_f32); RUN(mad_i24); RUN(mad_u24); RUN(lshl_add); RUN(add_u32); RUN(and_b32); RUN(xor_b32); RUN(lshr); RUN(bfe);
     RUN(mov); RUN(cndmask); RUN(mul_lo); RUN(mul_hi); RUN(rcp); RUN(sqrt); RUN(exp);
+    RUN(fma_mix_lo); RUN(fma_mix_hi); RUN(fma_mix_2h); RUN(cvt_f32_f16); RUN(perm);
     return 0;
 }

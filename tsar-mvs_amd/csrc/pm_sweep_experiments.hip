@@ -13,14 +13,17 @@ int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& a, con
     const bool strict = hs.flags & TSAR_FLAG_STRICT_DIV;
     if (!(hs.use_quad && hs.hrad == 5 && hs.vrad == 5 && need <= 2) || (hs.flags & TSAR_FLAG_TEX_FILTER_8BIT)) return TSAR_OK;
 #define EXP(S, V) case V: *launched = 1; return launch_sweep_t<2, 5, S, true, V>(ctx, colour, a, b, c, sid, dp, dr)
+    // TSAR_VARIANT_NOW (read per launch): time a variant on a state the production kernels converged (tools/ab_converged.py) —
+    // the wrong-result variants never converge on their own and would be measured in the random-plane regime
+    const int variant = getenv("TSAR_VARIANT_NOW") ? atoi(getenv("TSAR_VARIANT_NOW")) : ctx->variant;
     if (strict) {
-        switch (ctx->variant) {
+        switch (variant) {
             EXP(true, 58);
             EXP(true, 50);
             default: return TSAR_OK;
         }
     }
-    switch (ctx->variant) {
+    switch (variant) {
         EXP(false, 762);       // 250 + gathers of line t+1 issued before line t is blended
         EXP(false, 655610);    // buffer loads + division-free corner test
         EXP(false, 131290);    // buffer loads, no wave priority
@@ -30,6 +33,8 @@ int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& a, con
         EXP(false, 33018);     // 250 + 16 x 4 lanes per wave
         EXP(false, 506);       // WRONG RESULTS: the instruction mix of pairing two taps into one 16-byte gather
         EXP(false, 254);       // WRONG RESULTS: 250 without gathers (texel bits synthesised from the address): the VALU floor
+        EXP(false, 131322);    // the production buffer-load loop in EVERY launch (the library uses it from the third sweep on)
+        EXP(false, 2228474);   // WRONG RESULTS: 131322 with 8-byte loads and a v_fma_mix_f32 blend: the instruction mix of a half-float difference texture
         EXP(false, 1048826);   // WRONG RESULTS: 250 with every gather replaced by an LDS read: the ceiling of an LDS-staged source patch
         EXP(false, 2);
         EXP(false, 6);
