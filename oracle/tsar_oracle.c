@@ -45,7 +45,7 @@
 #define ORC_FLAG_TEX_FILTER_8BIT (1u << 5)
 #define ORC_FLAG_FIX_INIT_RADIUS (1u << 6) /* gipuma_init_cu2 on the sweeps' window instead of its own box / 2 (gipuma.cu:693-694) */
 /* S7: the arithmetic of the HIP library's default ("fast") mode, restated so that the mode bench.py times can be checked bit for
- * bit too, not only statistically.  It is the reference's algorithm with five ROUNDING liberties, none of which changes which
+ * bit too, not only statistically.  It is the reference's algorithm with six ROUNDING liberties, none of which changes which
  * operations are done on which data:
  *   (1) the per-tap perspective divide is one reciprocal and two multiplies, u = X * rcp(Z), v = Y * rcp(Z), where rcp is the
  *       GPU's v_rcp_f32 (1 ulp) — a hardware function, so the oracle evaluates it from a table of its 2^23 mantissa results that the
@@ -56,7 +56,9 @@
  *   (4) positions are clamped to [0, w - 1] x [0, h - 1] instead of [-1, w] x [-1, h] — the same sample bit for bit (edge
  *       replication), so the oracle's bilinear() serves both;
  *   (5) ORC_FLAG_ROW_ORDER: the three source sums run over the window row by row (x fastest) instead of column by column
- *       (what the 8-bit-imagery kernels do; float imagery keeps columns).
+ *       (what the 8-bit-imagery kernels do; float imagery keeps columns);
+ *   (6) the bilinear blend as t00 + ax d1 + ay d2 + (ax ay) d3 over texel differences (bilinear_qd) instead of two
+ *       horizontal interpolations and a vertical one.
  * The strict mode (no flag) remains the restatement of the reference; this mode is pinned to it only through the tolerances
  * stated in tests/test_gpu_fast_mode.py. */
 #define ORC_FLAG_FAST_ARITH (1u << 7)
@@ -160,7 +162,11 @@ static inline float texel(const float *img, int w, int h, int x, int y) {
     return img[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)];
 }
 /* tex2D<float>(tex, u+0.5, v+0.5) with linear filtering, clamp addressing (main.cpp:1215-1219) */
-static inline float bilinear_q(const float *img, int w, int h, float u, float v, int q8) {
+static inline float bilinear_qd(const float *img, int w, int h, float u, float v, int q8, int diff);
+static inline float bilinear_q(const float *img, int w, int h, float u, float v, int q8) { return bilinear_qd(img, w, h, u, v, q8, 0); }
+/* diff (S7 (6), fast arithmetic only): the blend as t00 + ax d1 + ay d2 + (ax ay) d3 over the texel differences d1 = t10 - t00,
+ * d2 = t01 - t00, d3 = (t11 - t01) - d1 (exact integers on 8-bit imagery), three chained FMAs */
+static inline float bilinear_qd(const float *img, int w, int h, float u, float v, int q8, int diff) {
     u = fminf(fmaxf(u, -1.0f), (float)w);
     v = fminf(fmaxf(v, -1.0f), (float)h);
     float fu = floorf(u), fv = floorf(v);
@@ -169,6 +175,10 @@ static inline float bilinear_q(const float *img, int w, int h, float u, float v,
     int x0 = (int)fu, y0 = (int)fv;
     float t00 = texel(img, w, h, x0, y0), t10 = texel(img, w, h, x0 + 1, y0);
     float t01 = texel(img, w, h, x0, y0 + 1), t11 = texel(img, w, h, x0 + 1, y0 + 1);
+    if (diff) {
+        const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
+        return fmaf(ax * ay, d3, fmaf(ay, d2, fmaf(ax, d1, t00)));
+    }
     float top = fmaf(ax, t10 - t00, t00);
     float bot = fmaf(ax, t11 - t01, t01);
     return fmaf(ay, bot - top, top);
@@ -351,7 +361,7 @@ static float pm_cost_fast(const orc_state *s, int view, int x, int y, const floa
             const float ref_pix = texel(l, w, h, x + i, y + j);
             const float wt = orc_expf(-sqrtf((float)(i * i + j * j)) / 50.0f - fabsf(ref_pix - cen) / 18.0f);
             const float rz = rcp_gpu(s, Z);
-            const float src_pix = bilinear_q(r, w, h, X * rz, Y * rz, q8);
+            const float src_pix = bilinear_qd(r, w, h, X * rz, Y * rz, q8, 1);
             const float ws = wt * src_pix;
             sum_src += ws;
             sum_src_src = fmaf(ws, src_pix, sum_src_src);

@@ -28,7 +28,8 @@
 typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
 typedef const float __attribute__((address_space(1)))* global_f32_ptr;
 
-template <bool QUAD>
+// DIFF (fast arithmetic only, oracle S7 (6)): the blend as t00 + ax d1 + ay d2 + (ax ay) d3 over the texel differences
+template <bool QUAD, bool DIFF = false>
 DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u, float v, bool q8 = false) {
     // tex2D(tex, u + .5, v + .5), linear filter, clamp addressing (main.cpp:1215-1219).
     u = fminf(fmaxf(u, -1.0f), (float)w);
@@ -52,6 +53,10 @@ DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u
         const global_f32_ptr r0 = (global_f32_ptr)vw.img + (size_t)y0 * w;
         const global_f32_ptr r1 = (global_f32_ptr)vw.img + (size_t)y1 * w;
         t00 = r0[x0]; t10 = r0[x1]; t01 = r1[x0]; t11 = r1[x1];
+    }
+    if (DIFF) {
+        const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
+        return fma_(ax * ay, d3, fma_(ay, d2, fma_(ax, d1, t00)));
     }
     const float top = fma_(ax, t10 - t00, t00);
     const float bot = fma_(ax, t11 - t01, t01);
@@ -161,7 +166,7 @@ DEVFN float view_cost_generic(const DevScene* __restrict__ sc, const DevView& vw
                 u = X * rz;
                 v = Y * rz;
             }
-            const float s = sample_bilinear<QUAD>(vw, w, h, qp, u, v, (sc->flags & TSAR_FLAG_TEX_FILTER_8BIT) != 0);
+            const float s = sample_bilinear<QUAD, !STRICT>(vw, w, h, qp, u, v, (sc->flags & TSAR_FLAG_TEX_FILTER_8BIT) != 0);
             const float r = tile_value(tile[own + j * tw + i]);
             const float wt = wts[tap * BLK];
             const float ws = wt * s;

@@ -213,9 +213,15 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q[jj]));
-            const float top = fma_(ax[jj], t10 - t00, t00);
-            const float bot = fma_(ax[jj], t11 - t01, t01);
-            const float s = fma_(ay[jj], bot - top, top);
+            float s;
+            if (STRICT) {
+                const float top = fma_(ax[jj], t10 - t00, t00);
+                const float bot = fma_(ax[jj], t11 - t01, t01);
+                s = fma_(ay[jj], bot - top, top);
+            } else {                                            // fast arithmetic (oracle S7 (6)), see pm_tap_r5.h
+                const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
+                s = fma_(ax[jj] * ay[jj], d3, fma_(ay[jj], d2, fma_(ax[jj], d1, t00)));
+            }
             const float wt = wv[jj];
             const float ws = wt * s;
             sum_src += ws;

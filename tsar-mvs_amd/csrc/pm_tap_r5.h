@@ -182,9 +182,15 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q[jj]));
-            const float top = fma_(ax[jj], t10 - t00, t00);
-            const float bot = fma_(ax[jj], t11 - t01, t01);
-            float s = fma_(ay[jj], bot - top, top);
+            float s;
+            if (STRICT) {                                       // the reference's blend: two horizontal interpolations, one vertical
+                const float top = fma_(ax[jj], t10 - t00, t00);
+                const float bot = fma_(ax[jj], t11 - t01, t01);
+                s = fma_(ay[jj], bot - top, top);
+            } else {                                            // fast arithmetic (oracle S7 (6)): t00 + ax d1 + ay d2 + (ax ay) d3, exact integer differences
+                const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
+                s = fma_(ax[jj] * ay[jj], d3, fma_(ay[jj], d2, fma_(ax[jj], d1, t00)));
+            }
             // one wait per line, at its first tap: every LDS load of the line (six texels when they are D16 loads, three weight
             // pairs) was issued before the gathers, in order, and has long returned when the first gather does
             if (jj == 0) {
