@@ -39,6 +39,31 @@ int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, in
     return TSAR_OK;
 }
 
+// The same quads as four halfs per entry, (t00, d1 = t10 - t00, d2 = t01 - t00, d3 = t11 - t10 - t01 + t00): what the fast
+// arithmetic's blend t00 + ax d1 + ay d2 + (ax ay) d3 consumes (oracle S7 (6)).  All four are integers of magnitude <= 510, exact in
+// fp16, so three v_fma_mix_f32 read them straight out of the gathered 8 bytes — no byte converts, no subtractions (pm_tap_r5.h MIX).
+__global__ __launch_bounds__(EW_BLOCK) void build_dquad_kernel(const uint32_t* __restrict__ quad, uint2* __restrict__ dquad, int64_t n) {
+    for (int64_t k = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * EW_BLOCK) {
+        const uint32_t q = quad[k];
+        const int t00 = q & 0xff, t10 = (q >> 8) & 0xff, t01 = (q >> 16) & 0xff, t11 = q >> 24;
+        const _Float16 h0 = (_Float16)(float)t00, h1 = (_Float16)(float)(t10 - t00), h2 = (_Float16)(float)(t01 - t00), h3 = (_Float16)(float)(t11 - t10 - t01 + t00);
+        uint2 o;
+        o.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+        o.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+        dquad[k] = o;
+    }
+}
+int launch_build_dquad(tsar_ctx* ctx, const uint32_t* quad, uint2* dquad, int w, int h) {
+    const int64_t n = (int64_t)(w + 2) * (h + 2);
+    const int grid = (int)((n + EW_BLOCK - 1) / EW_BLOCK < 4096 ? (n + EW_BLOCK - 1) / EW_BLOCK : 4096);
+    {
+        ScopedKernelTimer tm(ctx, "build_quad");
+        hipLaunchKernelGGL(build_dquad_kernel, dim3(grid), dim3(EW_BLOCK), 0, ctx->stream, quad, dquad, n);
+    }
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
 // ---- plane <-> depth -------------------------------------------------------------------------
 #define PIXEL_LOOP_BEGIN                                                                             \
     const int w = sc->w, h = sc->h;                                                                  \

@@ -48,6 +48,9 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     if constexpr ((NB == 2 || NB == 4) && HR == 5)
     if (quad && !(ctx->hscene.flags & TSAR_FLAG_TEX_FILTER_8BIT) && (v == 250 || v == 122 || (v == 114 && NB == 2))) {   // (the 8-bit filter mode runs the general-window loop)
 #define SWEEP_R5(S, V, B) (buf ? launch_sweep_t<NB, 5, S, true, (V) | 131072, B>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<NB, 5, S, true, V, B>(ctx, colour, a, b, c, sid, dp, dr))
+        // fast mode, buffer-load launches: the half-float difference texture (pm_tap_r5.h MIX) when tsar_set_views built it
+        const bool mix = buf && !strict && v == 250 && ctx->hscene.n_sel > 0 && ctx->hscene.view[ctx->hscene.sel[0]].dquad != nullptr;
+#define SWEEP_R5_FAST250(B) (mix ? launch_sweep_t<NB, 5, false, true, 250 | 131072 | 2097152, B>(ctx, colour, a, b, c, sid, dp, dr) : SWEEP_R5(false, 250, B))
         if constexpr (NB == 2) {
             // small images: 128-thread workgroups (see SWEEP_SMALL_IMAGE_TILES); TSAR_BLOCK=128|256 forces a shape (A/B runs)
             const int tiles256 = ((ctx->hscene.w + PM_RW - 1) / PM_RW) * ((ctx->hscene.h + 15) / 16);
@@ -55,12 +58,13 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             if (const char* e = getenv("TSAR_BLOCK")) small = atoi(e) == 128;
             if (small && v != 114) {
                 if (strict) return SWEEP_R5(true, 122, 128);
-                return v == 250 ? SWEEP_R5(false, 250, 128) : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
+                return v == 250 ? SWEEP_R5_FAST250(128) : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
             }
             if (v == 114) return strict ? launch_sweep_t<2, 5, true, true, 114>(ctx, colour, a, b, c, sid, dp, dr) : launch_sweep_t<2, 5, false, true, 114>(ctx, colour, a, b, c, sid, dp, dr);
         }
         if (strict) return SWEEP_R5(true, 122, PM_BLOCK);
-        return v == 250 ? SWEEP_R5(false, 250, PM_BLOCK) : launch_sweep_t<NB, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+        return v == 250 ? SWEEP_R5_FAST250(PM_BLOCK) : launch_sweep_t<NB, 5, false, true, 122>(ctx, colour, a, b, c, sid, dp, dr);
+#undef SWEEP_R5_FAST250
 #undef SWEEP_R5
     }
     constexpr int NBG = NB == 4 ? 32 : NB;      // the one-tap-at-a-time kernels exist for 2 and 32 best views

@@ -17,6 +17,10 @@
 //           addresser scales the element index, the per-tap shift goes away (-0.65 % on a converged launch, +4 ms on the first
 //           sweep of a view, so the launcher uses it from the third sweep on).  No compiler builtin reaches idxen: the loads are
 //           issued by asm and their vmcnt waits are written out.
+//   MIX     with BUF, fast mode: the gather reads 8 bytes from the view's half-float difference texture (t00, t10 - t00, t01 - t00,
+//           t11 - t10 - t01 + t00; plane_kernels.hip build_dquad_kernel) and the fast arithmetic's blend t00 + ax d1 + ay d2 + (ax ay) d3
+//           is three v_fma_mix_f32 on the halfs in place: no byte converts, no subtractions (-7.5 issue units of a tap's 34).  Same
+//           values bit for bit as the byte-texture form of that blend, which the global-load launches (init, the first two sweeps) keep.
 // Always on (each measured, profiles/r01-r02): a line (six taps) per trip in three explicit phases — all six tap positions, all six
 // gathers, then unpack / blend / accumulate — so that six gathers are in flight per wave whatever the scheduler decides; the view's
 // quad-texture base (border offset folded in) pinned in SGPRs for the whole view; the line's six weights loaded at the top of the
@@ -25,10 +29,11 @@
 // BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread]).
 #pragma once
 
-template <bool STRICT, bool ROW, bool D16, bool BUF, int BLK>
+template <bool STRICT, bool ROW, bool D16, bool BUF, bool MIX, int BLK>
 DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, const unsigned short* tile, int tw, int own, const float* wts,
                          const PixelRef& pr, int x, int y, const float4& n4) {
     static_assert(!(STRICT && ROW), "the row-wise walk changes the summation order: fast mode only");
+    static_assert(!MIX || (BUF && !STRICT), "the half-float difference texture serves the fast arithmetic's blend through buffer loads");
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
     const int qorg = (qp + 1) << 2;          // byte offset of quad entry (0 + 1, 0 + 1)
     float H[9];
@@ -82,8 +87,14 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     u32x4s rsrc = {0u, 0u, 0u, 0u};
     if (BUF) {
         const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)qorg;
+        if (MIX) {                           // 8-byte entries of the difference texture, same pitch and border
+            const uint64_t da = (uint64_t)(uintptr_t)vw.dquad + 2 * (uint64_t)(uint32_t)qorg;
+            rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)da);
+            rsrc.y = __builtin_amdgcn_readfirstlane(((uint32_t)(da >> 32) & 0xffffu) | (8u << 16));  // base[47:32] | stride 8
+        } else {
         rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)qa);
         rsrc.y = __builtin_amdgcn_readfirstlane(((uint32_t)(qa >> 32) & 0xffffu) | (4u << 16));      // base[47:32] | stride 4
+        }
         rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)(qp * (h + 1) - 1));                       // records from entry (1, 1) on
         rsrc.w = 0x00020000u;                                                                         // 32-bit data format (gfx9 family)
         asm volatile("" : "+s"(rsrc));
@@ -118,6 +129,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
         }
         float ax[6], ay[6];
         uint32_t q[6];
+        uint64_t q2[6];                              // MIX: the tap's four halfs
         __builtin_amdgcn_s_setprio(3);               // a wave computing tap positions / issuing gathers goes ahead of waves that are blending
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 1: tap positions -> element index; phase 2: gathers
@@ -154,7 +166,9 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             // element index of quad entry (iv + 1, iu + 1) from entry (1, 1): one 24-bit multiply-add
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-            if (BUF) {
+            if (MIX) {
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 idxen" : "=v"(q2[jj]) : "v"(lin), "s"(rsrc));
+            } else if (BUF) {
                 asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
             } else {                                            // base already holds the border offset: the byte offset is a plain shift
                 const uint32_t off2 = (uint32_t)lin << 2;
@@ -167,7 +181,14 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;                           // the four texels: one convert each, no shifts/masks
-            if (BUF) {
+            if (MIX) {
+                if (jj == 0) asm("s_waitcnt vmcnt(5)" : "+v"(q2[0]) : "v"(q2[5]));
+                if (jj == 1) asm("s_waitcnt vmcnt(4)" : "+v"(q2[1]), "+v"(sum_src_src) : "v"(q2[5]));
+                if (jj == 2) asm("s_waitcnt vmcnt(3)" : "+v"(q2[2]), "+v"(sum_src_src) : "v"(q2[5]));
+                if (jj == 3) asm("s_waitcnt vmcnt(2)" : "+v"(q2[3]), "+v"(sum_src_src) : "v"(q2[5]));
+                if (jj == 4) asm("s_waitcnt vmcnt(1)" : "+v"(q2[4]), "+v"(sum_src_src) : "v"(q2[5]));
+                if (jj == 5) asm("s_waitcnt vmcnt(0)" : "+v"(q2[5]), "+v"(sum_src_src));
+            } else if (BUF) {
                 // the asm-issued gathers return in order: tap jj has 5 - jj behind it.  Not volatile (a volatile wait is
                 // scheduled with the loads, ahead of every blend); the q[5] input keeps each wait behind the issue of the last load, the
                 // accumulator behind the previous tap's blend
@@ -178,11 +199,21 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
                 if (jj == 4) asm("s_waitcnt vmcnt(1)" : "+v"(q[4]), "+v"(sum_src_src) : "v"(q[5]));
                 if (jj == 5) asm("s_waitcnt vmcnt(0)" : "+v"(q[5]), "+v"(sum_src_src));
             }
+            float s;
+            if (MIX) {
+                // t00 + ax d1 + ay d2 + (ax ay) d3 with the halfs read in place: three fused multiply-adds with one fp32 rounding
+                // each, the same values as the fp32 chain below (the halfs are exact integers)
+                const uint32_t lo = (uint32_t)q2[jj], hi = (uint32_t)(q2[jj] >> 32);
+                const float axay = ax[jj] * ay[jj];
+                float tt;
+                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tt) : "v"(ax[jj]), "v"(lo));          // ax * d1 + t00
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(tt) : "v"(ay[jj]), "v"(hi), "v"(tt));                // ay * d2 + .
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(s) : "v"(axay), "v"(hi), "v"(tt));    // (ax ay) * d3 + .
+            } else {
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q[jj]));
-            float s;
             if (STRICT) {                                       // the reference's blend: two horizontal interpolations, one vertical
                 const float top = fma_(ax[jj], t10 - t00, t00);
                 const float bot = fma_(ax[jj], t11 - t01, t01);
@@ -190,6 +221,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             } else {                                            // fast arithmetic (oracle S7 (6)): t00 + ax d1 + ay d2 + (ax ay) d3, exact integer differences
                 const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
                 s = fma_(ax[jj] * ay[jj], d3, fma_(ay[jj], d2, fma_(ax[jj], d1, t00)));
+            }
             }
             // one wait per line, at its first tap: every LDS load of the line (six texels when they are D16 loads, three weight
             // pairs) was issued before the gathers, in order, and has long returned when the first gather does
@@ -227,4 +259,5 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
 }
 
 // The variant numbers the production kernels are instantiated with (and which profiles name): bits 1, 4, 5, 6 always set.
-__host__ __device__ constexpr bool r5_production_variant(int V) { return V == 114 || V == 122 || V == 250 || V == (114 | 131072) || V == (122 | 131072) || V == (250 | 131072); }
+// + 2097152 (with 250 | 131072): MIX
+__host__ __device__ constexpr bool r5_production_variant(int V) { return V == 114 || V == 122 || V == 250 || V == (114 | 131072) || V == (122 | 131072) || V == (250 | 131072) || V == (250 | 131072 | 2097152); }

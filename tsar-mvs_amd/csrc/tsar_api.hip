@@ -252,6 +252,7 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
     ctx->variant = probe_d16_hi_zeroes(ctx) ? 250 : 114;
     if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
     if (const char* e = getenv("TSAR_BUFFER_GATHER")) ctx->buffer_gather = e[0] != '0';
+    if (const char* e = getenv("TSAR_MIX_GATHER")) ctx->mix_gather = e[0] != '0';
     if (const char* e = getenv("TSAR_STRIP")) ctx->strip_w = atoi(e);
     if (const char* e = getenv("TSAR_DEBUG_COUNTERS"))
         if (e[0] == '1' && hipMalloc((void**)&ctx->dbg, 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(ctx->dbg, 0, 8 * sizeof(unsigned long long));
@@ -262,8 +263,10 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
 static void free_views(tsar_ctx* ctx) {
     for (auto& p : ctx->img) dev_free(p);
     for (auto& p : ctx->quad) dev_free(p);
+    for (auto& p : ctx->dquad) dev_free(p);
     ctx->img.clear();
     ctx->quad.clear();
+    ctx->dquad.clear();
 }
 static void free_planes(tsar_ctx* ctx) {
     for (int b = 0; b < 2; b++) { dev_free(ctx->buf[b].c); dev_free(ctx->buf[b].n4); }
@@ -358,6 +361,7 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     sc.w = w; sc.h = h; sc.quad_pitch = w + 2;
     if ((int)ctx->img.size() < n_views) ctx->img.resize(n_views, nullptr);
     if ((int)ctx->quad.size() < n_views) ctx->quad.resize(n_views, nullptr);
+    if ((int)ctx->dquad.size() < n_views) ctx->dquad.resize(n_views, nullptr);
     struct DevInt {   // freed on every exit path
         int* p = nullptr;
         ~DevInt() { if (p) hipFree(p); }
@@ -375,9 +379,20 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     TSAR_HIP_TRY(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     sc.use_quad = hflag ? 0 : 1;
-    for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; }
+    for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; sc.view[v].dquad = nullptr; }
     if (!sc.use_quad)
         for (auto& q : ctx->quad) dev_free(q);              // (float imagery: the textures are not used; re-allocated if a later call needs them)
+    // Fast mode's converged sweeps of the box-11 loop (buffer gathers, from the third sweep of a run on) read the source views from a
+    // second texture with half-float differences (pm_tap_r5.h MIX): 8 bytes per texel quad, source views only.
+    const bool want_dquad = sc.use_quad && !(ctx->params.flags & (TSAR_FLAG_STRICT_DIV | TSAR_FLAG_TEX_FILTER_8BIT)) && ctx->buffer_gather && ctx->mix_gather &&
+                            ctx->variant == 250 && ctx->params.box_hsize >= 11 && ctx->params.box_hsize <= 12 && ctx->params.box_vsize >= 11 && ctx->params.box_vsize <= 12;
+    for (int v = 1; v < n_views; v++) {
+        if (!want_dquad) { dev_free(ctx->dquad[v]); continue; }
+        if (!ctx->dquad[v]) TRY(dev_alloc(ctx, &ctx->dquad[v], (size_t)(w + 2) * (h + 2)));
+        TRY(launch_build_dquad(ctx, ctx->quad[v], ctx->dquad[v], w, h));
+        sc.view[v].dquad = ctx->dquad[v];
+    }
+    TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     derive_cameras(ctx, cams);
     // Can the matching kernels run this window?  8-bit imagery shares one weight table per workgroup (pm_core_lut.h): any box whose
     // taps have <= TSAR_LUT_MAX_CLASSES distinct distances (every square box; rectangular ones unless their radii have mixed

@@ -27,6 +27,7 @@ struct DevView {
     float pad2_;
     const float* img;        // [h][w] float gray
     const uint32_t* quad;    // [(h+2)][(w+2)] packed 2x2 texel quads (8-bit images only), see plane_kernels.hip build_quad_kernel
+    const uint2* dquad;      // [(h+2)][(w+2)] the same quads as four halfs (t00, t10 - t00, t01 - t00, t11 - t10 - t01 + t00): fast mode's converged sweeps (pm_tap_r5.h MIX), else null
 };
 
 // Reference camera block (camera.h:9-33 for cameras[REFERENCE]).
@@ -103,6 +104,7 @@ struct tsar_ctx {
     DevScene* dscene = nullptr;  // device copy
     std::vector<float*> img;     // device images (owned)
     std::vector<uint32_t*> quad;
+    std::vector<uint2*> dquad;   // half-float difference textures (fast mode, box-11 loop, buffer gathers), see DevView
     PlaneBuf buf[2]{};           // buf[0] is the canonical state outside tsar_pm_iterate
     float *ratio = nullptr, *depth = nullptr, *scale = nullptr, *lrdiff = nullptr, *confid = nullptr, *fakedepth = nullptr;
     int32_t *beview = nullptr, *canny = nullptr;
@@ -118,6 +120,7 @@ struct tsar_ctx {
     // timing
     bool lds_sweep = false;      // TSAR_LDS_SWEEP=1: LDS-patch form of the sweep (pm_sweep_lds.hip); bit-exact, not yet faster
     int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); tsar_create picks 250 (med3/fract + D16 window loads + clamp-free loop for in-image windows + wave priority + SGPR-pinned texture base and line-top weight loads + row-wise window walk in fast mode; strict mode runs it as 122, the oracle's column order) when the D16 probe passes, else 114
+    bool mix_gather = true;      // TSAR_MIX_GATHER=0: keep the byte texture for the buffer-load launches too (pm_tap_r5.h MIX off)
     bool buffer_gather = true;   // TSAR_BUFFER_GATHER=0: the fast tap loop's gathers as global loads + a shift instead of structured buffer loads
     int strip_w = -1;            // TSAR_STRIP=n: width in tiles of the strips the sweep walks (pm_core.h strip_tile), 0 = row-major,
                                  // -1 = automatic: one vertical band of the image per XCD (see strip_width)
@@ -183,6 +186,7 @@ struct ScopedKernelTimer {
 
 // ---- launchers implemented in the .hip files -----------------------------------------------------
 int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, int h, int* nonintegral_flag);
+int launch_build_dquad(tsar_ctx* ctx, const uint32_t* quad, uint2* dquad, int w, int h);
 int launch_pm_init(tsar_ctx* ctx);
 bool probe_d16_hi_zeroes(tsar_ctx* ctx);   // pm_sweep.hip
 int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
