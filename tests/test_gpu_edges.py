@@ -57,16 +57,20 @@ def _cases():
     return out
 
 
-def _matcher(flags, buffer_gather):
-    old = os.environ.get("TSAR_BUFFER_GATHER")
-    os.environ["TSAR_BUFFER_GATHER"] = "1" if buffer_gather else "0"       # read by tsar_create
+def _matcher(flags, buffer_gather, mix_gather=True):
+    """buffer_gather: the sweeps' gathers as structured buffer loads (from the third sweep on) or global loads; mix_gather: the
+    buffer-load launches read the half-float difference texture (pm_tap_r5.h MIX) or the byte texture.  Read by tsar_create."""
+    old = {k: os.environ.get(k) for k in ("TSAR_BUFFER_GATHER", "TSAR_MIX_GATHER")}
+    os.environ["TSAR_BUFFER_GATHER"] = "1" if buffer_gather else "0"
+    os.environ["TSAR_MIX_GATHER"] = "1" if mix_gather else "0"
     try:
         m = api.Matcher()
     finally:
-        if old is None:
-            os.environ.pop("TSAR_BUFFER_GATHER")
-        else:
-            os.environ["TSAR_BUFFER_GATHER"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
     imgs, K, R, t = _scene()
     m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=1e-3, depth_max=1e6, seed=3, flags=flags))
     m.set_views(imgs, K, R, t)
@@ -102,7 +106,7 @@ def block_shape(request):
 def test_border_and_behind_camera_taps_all_gather_forms(strict, block_shape):
     imgs, K, R, t = _scene()
     flags = api.FLAG_STRICT_DIV if strict else 0
-    mb, mg = _matcher(flags, True), _matcher(flags, False)
+    mb, mg, mq = _matcher(flags, True), _matcher(flags, False), _matcher(flags, True, mix_gather=False)
     n_border_pixels = 0
     for view, z0 in _cases():
         if z0 < 0 and view != 3:
@@ -113,17 +117,18 @@ def test_border_and_behind_camera_taps_all_gather_forms(strict, block_shape):
             orc.set_rcp_table(ol.rcp_table_from_device(mb))     # fast mode: against the oracle's restatement of the fast arithmetic
         c_ref = orc.pm_cost_planes(planes)[0]
         res = {}
-        for name, m in (("buffer", mb), ("global", mg)):
+        for name, m in (("buffer", mb), ("global", mg), ("bytes", mq)):
             m.set_view_subset([view])
             res[name + "_full"] = m.pm_cost_planes(planes)[0]
             res[name + "_sweep"] = _sweep_cost(m, planes)
-        # the two gather forms, and the two kernels, agree bit for bit in either arithmetic
-        for k in ("buffer_sweep", "global_full", "global_sweep"):
+        # the three gather forms (buffer loads from the half-float difference texture, buffer loads from the byte texture, global
+        # loads), and the two kernels, agree bit for bit in either arithmetic
+        for k in ("buffer_sweep", "global_full", "global_sweep", "bytes_sweep"):
             assert np.array_equal(res["buffer_full"], res[k]), (view, z0, k)
         assert np.array_equal(res["buffer_sweep"], c_ref), (view, z0)          # either mode: the oracle run in the same arithmetic
         n_border_pixels += int((c_ref < 2.0).sum())
     assert n_border_pixels > 1000        # the cases score real windows, not MAXCOST everywhere
-    mb.close(); mg.close()
+    mb.close(); mg.close(); mq.close()
 
 
 @pytest.mark.parametrize("strict", [True, False])

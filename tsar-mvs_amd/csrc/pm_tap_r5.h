@@ -21,6 +21,9 @@
 //           t11 - t10 - t01 + t00; plane_kernels.hip build_dquad_kernel) and the fast arithmetic's blend t00 + ax d1 + ay d2 + (ax ay) d3
 //           is three v_fma_mix_f32 on the halfs in place: no byte converts, no subtractions (-7.5 issue units of a tap's 34).  Same
 //           values bit for bit as the byte-texture form of that blend, which the global-load launches (init, the first two sweeps) keep.
+//           (Strict mode can form the reference's blend from the same halfs bit-exactly — t10 - t00 is stored, t01 and t11 - t01 are
+//           one exact v_fma_mix_f32 each, -4.5 issue units per tap — and was measured SLOWER, 48.1 -> 51.6 ms per launch: its
+//           column-order walk touches six texture rows per lane and trip, and 8-byte entries double that footprint.  Not kept.)
 // Always on (each measured, profiles/r01-r02): a line (six taps) per trip in three explicit phases — all six tap positions, all six
 // gathers, then unpack / blend / accumulate — so that six gathers are in flight per wave whatever the scheduler decides; the view's
 // quad-texture base (border offset folded in) pinned in SGPRs for the whole view; the line's six weights loaded at the top of the
