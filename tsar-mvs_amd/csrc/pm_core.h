@@ -209,7 +209,7 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
         float c;
         // V names the tap loop: bit 10 = the general-window loop (chunk length in bits 11-13), a production variant of the box-11
         // loop (pm_tap_r5.h), 0 = the generic one-tap loop; anything else exists in the experiments build only
-        if constexpr ((V & 1024) != 0) c = view_cost_lut<STRICT, (V >> 11) & 7, (V & 131072) != 0 && !STRICT>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
+        if constexpr ((V & 1024) != 0) c = view_cost_lut<STRICT, (V >> 11) & 7, (V & 131072) != 0 && !STRICT, (V & 2097152) != 0 && !STRICT>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         else if constexpr (QUAD && HR == 5 && r5_production_variant(V))
             c = view_cost_r5<STRICT, (V & 128) != 0 && !STRICT, (V & 8) != 0, (V & 131072) != 0, (V & 2097152) != 0, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
 #ifdef TSAR_EXPERIMENTS

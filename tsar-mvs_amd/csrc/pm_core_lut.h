@@ -78,7 +78,7 @@ DEVFN void lut_wait_lds(float (&r)[CH], uint32_t after) {
     else if constexpr (CH == 5) asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "v"(after));
     else asm("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "v"(after));
 }
-template <bool STRICT, int CH, bool BUF = false>
+template <bool STRICT, int CH, bool BUF = false, bool MIX = false>
 DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, const unsigned short* tile, int tw, int own, const float* lut,
                           const PixelRef& pr, int x, int y, const float4& n4) {
     constexpr bool ROW = !STRICT;                           // fast mode walks window rows (see pm_core.h, variant bit 7)
@@ -121,7 +121,15 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     // descriptor — see pm_core.h, variant bit 17
     typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
     u32x4s rsrc = {0u, 0u, 0u, 0u};
-    if constexpr (BUF) {
+    static_assert(!MIX || (BUF && !STRICT), "the half-float difference texture serves the fast arithmetic's blend through buffer loads");
+    if constexpr (MIX) {                                    // 8-byte entries of the difference texture (pm_tap_r5.h MIX), same pitch and border
+        const uint64_t da = (uint64_t)(uintptr_t)vw.dquad + 2 * (uint64_t)(uint32_t)((qp + 1) << 2);
+        rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)da);
+        rsrc.y = __builtin_amdgcn_readfirstlane(((uint32_t)(da >> 32) & 0xffffu) | (8u << 16));
+        rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)(qp * (h + 1) - 1));
+        rsrc.w = 0x00020000u;
+        asm volatile("" : "+s"(rsrc));
+    } else if constexpr (BUF) {
         rsrc.x = qb_lo;
         rsrc.y = __builtin_amdgcn_readfirstlane((qb_hi & 0xffffu) | (4u << 16));
         rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)(qp * (h + 1) - 1));
@@ -138,6 +146,7 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         float r[CH], ax[CH], ay[CH], wv[CH];
         uint32_t q[CH], off_last = 0;
+        uint64_t q2[CH];                                    // MIX: the tap's four halfs
         float yj0 = 0.f;
         if constexpr (ROW) {
             // the chunk's reference texels, each loaded into bits 31:16 of a register = its fp32 value (pm_core.h, variant bit 3);
@@ -183,7 +192,10 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             }
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-            if constexpr (BUF) {
+            if constexpr (MIX) {
+                off_last = (uint32_t)lin;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 idxen" : "=v"(q2[jj]) : "v"(lin), "s"(rsrc));
+            } else if constexpr (BUF) {
                 off_last = (uint32_t)lin;
                 asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
             } else {
@@ -207,13 +219,22 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
 #pragma unroll
         for (int jj = 0; jj < CH; jj++) {                   // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;
+            float s;
+            if constexpr (MIX) {
+                asm("s_waitcnt vmcnt(%3)" : "+v"(q2[jj]), "+v"(sum_src_src) : "v"(q2[CH - 1]), "n"(CH - 1 - jj));
+                const uint32_t lo = (uint32_t)q2[jj], hi = (uint32_t)(q2[jj] >> 32);
+                const float axay = ax[jj] * ay[jj];
+                float tt;
+                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tt) : "v"(ax[jj]), "v"(lo));          // ax * d1 + t00
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(tt) : "v"(ay[jj]), "v"(hi), "v"(tt));                // ay * d2 + .
+                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(s) : "v"(axay), "v"(hi), "v"(tt));    // (ax ay) * d3 + .
+            } else {
             if constexpr (BUF)      // the asm-issued gathers return in order: tap jj has CH - 1 - jj behind it (waits chained, pm_core.h)
                 asm("s_waitcnt vmcnt(%3)" : "+v"(q[jj]), "+v"(sum_src_src) : "v"(q[CH - 1]), "n"(CH - 1 - jj));
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(t11) : "v"(q[jj]));
-            float s;
             if (STRICT) {
                 const float top = fma_(ax[jj], t10 - t00, t00);
                 const float bot = fma_(ax[jj], t11 - t01, t01);
@@ -221,6 +242,7 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             } else {                                            // fast arithmetic (oracle S7 (6)), see pm_tap_r5.h
                 const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
                 s = fma_(ax[jj] * ay[jj], d3, fma_(ay[jj], d2, fma_(ax[jj], d1, t00)));
+            }
             }
             const float wt = wv[jj];
             const float ws = wt * s;

@@ -382,10 +382,9 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; sc.view[v].dquad = nullptr; }
     if (!sc.use_quad)
         for (auto& q : ctx->quad) dev_free(q);              // (float imagery: the textures are not used; re-allocated if a later call needs them)
-    // Fast mode's converged sweeps of the box-11 loop (buffer gathers, from the third sweep of a run on) read the source
-    // views from a second texture with half-float differences (pm_tap_r5.h MIX): 8 bytes per texel quad, source views only.
-    const bool want_dquad = sc.use_quad && !(ctx->params.flags & (TSAR_FLAG_STRICT_DIV | TSAR_FLAG_TEX_FILTER_8BIT)) && ctx->buffer_gather && ctx->mix_gather &&
-                            ctx->variant == 250 && ctx->params.box_hsize >= 11 && ctx->params.box_hsize <= 12 && ctx->params.box_vsize >= 11 && ctx->params.box_vsize <= 12;
+    // Fast mode's converged sweeps (buffer gathers, from the third sweep of a run on; the box-11 loop and the general-window loop) read
+    // the source views from a second texture with half-float differences (pm_tap_r5.h MIX): 8 bytes per texel quad, source views only.
+    const bool want_dquad = sc.use_quad && !(ctx->params.flags & TSAR_FLAG_STRICT_DIV) && ctx->buffer_gather && ctx->mix_gather && ctx->variant == 250;
     for (int v = 1; v < n_views; v++) {
         if (!want_dquad) { dev_free(ctx->dquad[v]); continue; }
         if (!ctx->dquad[v]) TRY(dev_alloc(ctx, &ctx->dquad[v], (size_t)(w + 2) * (h + 2)));
