@@ -31,12 +31,17 @@ def main():
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--box", type=int, default=11)
     ap.add_argument("--n_best", type=int, default=1)
+    ap.add_argument("--mode", choices=["strict", "fast"], default="strict",
+                    help="strict: the reference's arithmetic; fast: the default arithmetic against the oracle's restatement of it (S7, device rcp table)")
     args = ap.parse_args()
     sc = synth.make_scene(args.width, args.height, args.views, device="cuda", seed=1234)
     images = [im.cpu().numpy() for im in sc.images]
-    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=args.box, n_best=args.n_best)
-    m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024, flags=api.FLAG_STRICT_DIV)
-    report = {"workload": f"{args.width}x{args.height}, 1 ref + {args.views} src views, box {args.box}, n_best {args.n_best}, strict mode vs CPU oracle",
+    fast = args.mode == "fast"
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=args.box, n_best=args.n_best, flags=ol.FLAGS_FAST_8BIT_IMAGERY if fast else 0)
+    m = api.matcher_from_scene(sc, box=args.box, n_best=args.n_best, seed=2024, flags=0 if fast else api.FLAG_STRICT_DIV)
+    if fast:
+        orc.set_rcp_table(ol.rcp_table_from_device(m))
+    report = {"workload": f"{args.width}x{args.height}, 1 ref + {args.views} src views, box {args.box}, n_best {args.n_best}, {args.mode} mode vs the CPU oracle in the same arithmetic",
               "steps": []}
 
     def compare(tag, t_cpu, t_gpu):
@@ -64,6 +69,8 @@ def main():
     out_same = bool(np.array_equal(res["depth"], d_ref[..., 3]) and np.array_equal(res["normal"], d_ref[..., :3]))
     report["output_maps_bit_identical"] = out_same
     report["all_bit_identical"] = bool(ok and out_same)
+    if fast:
+        report["rcp_operands_outside_table"] = bool(orc.rcp_out_of_range)
     gt = sc.gt_depth.cpu().numpy()
     report["frac_depth_within_1pct_of_gt"] = float((np.abs(res["depth"] - gt) / gt < 0.01).mean())
     m.close()
