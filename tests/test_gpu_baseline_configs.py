@@ -348,22 +348,25 @@ def test_degenerate_inputs_bit_exact():
 
 @pytest.mark.parametrize("w,h,n_best,box", [(101, 67, 1, 11), (640, 480, 1, 11), (2016, 1344, 3, 11), (333, 222, 2, 19), (640, 480, 5, 7), (320, 200, 1, 9)])
 def test_structured_buffer_gathers_change_no_bit(monkeypatch, w, h, n_best, box):
-    """the fast tap loop issues its gathers as structured buffer loads (pm_core.h variant bit 17: the addresser scales the
-    element index); TSAR_BUFFER_GATHER=0 keeps global loads and a shift.  Same arithmetic: whole fast-mode runs must agree bit
-    for bit, for both workgroup shapes and both best-N selections of the box-11 loop and for the general-window loop (chunks of
-    4 / 5 / 6 taps)"""
+    """from the third sweep of a run on the fast tap loops issue their gathers as structured buffer loads (pm_tap_r5.h BUF: the
+    addresser scales the element index) from the half-float difference texture (MIX: v_fma_mix_f32 blend, no byte converts);
+    TSAR_MIX_GATHER=0 keeps the byte texture for them, TSAR_BUFFER_GATHER=0 keeps global loads and a shift in every launch.  Same
+    arithmetic: whole fast-mode runs must agree bit for bit in all three forms, for both workgroup shapes and both best-N
+    selections of the box-11 loop and for the general-window loop (chunks of 4 / 5 / 6 taps)"""
     sc = synth.make_scene(w, h, 4, device="cuda" if w > 1000 else "cpu", seed=19)
     outs = []
-    for knob in ("1", "0"):
-        monkeypatch.setenv("TSAR_BUFFER_GATHER", knob)
+    for buf, mix in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("TSAR_BUFFER_GATHER", buf)
+        monkeypatch.setenv("TSAR_MIX_GATHER", mix)
         m = api.matcher_from_scene(sc, seed=5, n_best=n_best, box=box)
         m.pm_init()
         m.pm_iterate(3)
         planes, cost, bv, ratio = m.get_plane()
         outs.append((planes.view(np.uint32).copy(), cost.view(np.uint32).copy(), bv.copy(), ratio.view(np.uint32).copy()))
         m.close()
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_live_path_full_size_bit_exact():
