@@ -160,7 +160,6 @@ DEVFN float view_cost_variants(const DevScene* __restrict__ sc, const DevView& v
         }
         float ax[6], ay[6];
         uint32_t q[6];
-        uint64_t q2[6];                                          // EXPERIMENT bit 21: 8-byte entries (four halfs), see phase 3
         if (V & 32) __builtin_amdgcn_s_setprio(3);               // a wave computing tap positions / issuing gathers goes ahead of waves that are blending
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 1: tap positions -> byte offsets; phase 2: gathers
@@ -214,11 +213,6 @@ DEVFN float view_cost_variants(const DevScene* __restrict__ sc, const DevView& v
             if (!(V & 64)) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(lin), "s"(qorg));
             if ((V & 131072) && (V & 262144)) {
                 q[jj] = (uint32_t)lin;                          // experiment (bit 18): the six loads issued back to back after the loop
-            } else if ((V & 131072) && (V & 2097152)) {
-                // EXPERIMENT (TSAR_VARIANT=2228474, wrong results): the instruction mix of a half-float texture with 8-byte entries
-                // (t00, t10 - t00, t01 - t00, t11 - t10 - t01 + t00) blended by three v_fma_mix_f32 — no byte converts, no
-                // subtractions.  Loads 8 bytes from the 4-byte texture (footprint and coalescing as today: an upper bound)
-                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 idxen" : "=v"(q2[jj]) : "v"(lin), "s"(rsrc));
             } else if (V & 131072) {
                 asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
             } else if (V & 64) {                                // base already holds the border offset: the byte offset is a plain shift
@@ -255,14 +249,6 @@ DEVFN float view_cost_variants(const DevScene* __restrict__ sc, const DevView& v
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;                           // the four texels: one convert each, no shifts/masks
-            if ((V & 131072) && (V & 2097152)) {
-                if (jj == 0) asm("s_waitcnt vmcnt(5)" : "+v"(q2[0]) : "v"(q2[5]));
-                if (jj == 1) asm("s_waitcnt vmcnt(4)" : "+v"(q2[1]), "+v"(sum_src_src) : "v"(q2[5]));
-                if (jj == 2) asm("s_waitcnt vmcnt(3)" : "+v"(q2[2]), "+v"(sum_src_src) : "v"(q2[5]));
-                if (jj == 3) asm("s_waitcnt vmcnt(2)" : "+v"(q2[3]), "+v"(sum_src_src) : "v"(q2[5]));
-                if (jj == 4) asm("s_waitcnt vmcnt(1)" : "+v"(q2[4]), "+v"(sum_src_src) : "v"(q2[5]));
-                if (jj == 5) asm("s_waitcnt vmcnt(0)" : "+v"(q2[5]), "+v"(sum_src_src));
-            } else
             if (V & 131072) {
                 // the asm-issued gathers return in order: tap jj has 5 - jj behind it.  Not volatile (a volatile wait is
                 // scheduled with the loads, ahead of every blend); the q[5] input keeps each wait behind the issue of the last load, the
@@ -277,14 +263,7 @@ DEVFN float view_cost_variants(const DevScene* __restrict__ sc, const DevView& v
             if ((V & 64) && (V & 1048576))     // the LDS-read experiment: LDS returns in order, tap jj has 5 - jj reads behind it
                 asm("s_waitcnt lgkmcnt(%2)" : "+v"(q[jj]), "+v"(sum_src_src) : "n"(5 - jj), "v"(q[5]));
             float s;
-            if ((V & 131072) && (V & 2097152)) {
-                const uint32_t lo = (uint32_t)q2[jj], hi = (uint32_t)(q2[jj] >> 32);
-                const float axay = ax[jj] * ay[jj];
-                float tt;
-                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tt) : "v"(ax[jj]), "v"(lo));   // t00 + ax d1
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(tt) : "v"(ay[jj]), "v"(hi), "v"(tt));         // + ay d2
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(s) : "v"(axay), "v"(hi), "v"(tt));   // + ax ay d3
-            } else {
+            {
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(t01) : "v"(q[jj]));

@@ -34,7 +34,7 @@ int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& a, con
         EXP(false, 506);       // WRONG RESULTS: the instruction mix of pairing two taps into one 16-byte gather
         EXP(false, 254);       // WRONG RESULTS: 250 without gathers (texel bits synthesised from the address): the VALU floor
         EXP(false, 131322);    // the production buffer-load loop in EVERY launch (the library uses it from the third sweep on)
-        EXP(false, 2228474);   // WRONG RESULTS: 131322 with 8-byte loads and a v_fma_mix_f32 blend: the instruction mix of a half-float difference texture
+        EXP(false, 2228474);   // the production difference-texture loop (pm_tap_r5.h MIX) in EVERY launch (needs the context's dquad textures)
         EXP(false, 1048826);   // WRONG RESULTS: 250 with every gather replaced by an LDS read: the ceiling of an LDS-staged source patch
         EXP(false, 2);
         EXP(false, 6);
