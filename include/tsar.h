@@ -257,7 +257,14 @@ void tsar_default_fusion_params(tsar_fusion_params* p);
  * one point cloud.  cams: K and world->camera R, t per view; gray: the views' images (point colour).  The
  * source views of view v are src_idx[src_off[v] .. src_off[v+1]) (pair.txt as CSR).  points_out: up to `cap`
  * records of 9 floats (x y z, nx ny nz, gray, number of agreeing views, reference view), in view order then
- * raster order; *n_points_out is the number found (may exceed cap).  Context-free: runs on `device`. */
+ * raster order; *n_points_out is the number found (may exceed cap).
+ * tsar_fuse_ctx runs on the context's device and stream and takes every temporary from the context's scratch arena (no device
+ * allocation from the second call of a size on); tsar_fuse is the context-free form for a one-shot fuser process: it creates a
+ * context on `device` for the duration of the call. */
+int tsar_fuse_ctx(tsar_ctx* ctx, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth,
+                  const float* const* normal_world, const float* const* gray, int mem, const int32_t* src_off,
+                  const int32_t* src_idx, const tsar_fusion_params* params, float* points_out, int64_t cap,
+                  int64_t* n_points_out);
 int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth,
               const float* const* normal_world, const float* const* gray, int mem, const int32_t* src_off,
               const int32_t* src_idx, const tsar_fusion_params* params, float* points_out, int64_t cap,

@@ -174,21 +174,6 @@ def test_tap_loop_without_d16_loads_bit_exact(monkeypatch, variant):
     assert np.max(np.abs(c_fast - orc.c)) <= 1e-3
 
 
-def test_lds_patch_sweep_variant_bit_exact(monkeypatch):
-    """the opt-in LDS-patch form of the sweep (pm_sweep_lds.hip, TSAR_LDS_SWEEP=1): slower than the default kernel
-     but kept as a measured alternative — it must produce the oracle's bits too"""
-    if b"+experiments" not in api.load_library().tsar_version():
-        pytest.skip("the LDS-patch sweep is an experiment: built only with `make TSAR_EXPERIMENTS=1` (tsar-mvs_amd/csrc/Makefile)")
-    monkeypatch.setenv("TSAR_LDS_SWEEP", "1")
-    sc = synth.make_scene(192, 128, 4, seed=11)
-    orc = _oracle(sc, seed=5)
-    orc.pm_init()
-    orc.pm_iterate(2)
-    m = api.matcher_from_scene(sc, seed=5, flags=api.FLAG_STRICT_DIV)
-    m.pm_init()
-    m.pm_iterate(2)
-    _assert_state_equal(m, orc)
-    m.close()
 
 
 @pytest.mark.parametrize("box,n_best,n_src", [(19, 2, 3), (7, 1, 3), (11, 1, 1), (11, 3, 5), (5, 1, 2), (9, 1, 2), (15, 4, 5), (27, 1, 2), ((13, 7), 2, 3), (11, 4, 5), (11, 5, 5), (19, 6, 6), (7, 5, 5)])

@@ -1,7 +1,8 @@
 """Multi-rank control flow of bench.py on ONE GPU (the 8-GPU legs are the driver's to run).
 
-bench.py --gpus 2 is launched exactly as the driver launches it (python -m torch.distributed.run, one rank per process,
-fresh processes), with TSAR_BENCH_BACKEND=gloo so that both ranks may share the single device of the test box: each
+bench.py --gpus 2 is launched both ways the driver may type it — under python -m torch.distributed.run (one rank per process,
+fresh processes), and as plain `python bench.py --gpus 2`, which starts the ranks itself as a child process before touching the
+GPU — with the gloo transport (TSAR_BENCH_BACKEND=gloo, or chosen by bench.py when ranks outnumber devices) so that both ranks may share the single device of the test box: each
 rank matches its own reference view, the results are gathered to rank 0 through the double-buffered asynchronous
 gather, and --verify-gather checks on rank 0 that every gathered buffer equals the sending rank's own output bit for
 bit.  What this cannot show is RCCL itself moving the bytes over xGMI — that row stays "unmeasured on hardware".
@@ -27,12 +28,20 @@ def _free_port():
     return p
 
 
-def _run_bench(world, extra, env_extra=None, timeout=600, backend="gloo"):
+def _run_bench(world, extra, env_extra=None, timeout=600, backend="gloo", as_typed=False):
+    """as_typed: plain `python bench.py --gpus N ...` with no launcher and no TSAR_BENCH_* in the environment — bench.py starts the
+    ranks itself (and, on a box with fewer devices than ranks, picks the gloo rehearsal transport itself)"""
     env = dict(os.environ)
-    env.update({"TSAR_BENCH_BACKEND": backend, "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "2"})
+    if as_typed:
+        for k in ("TSAR_BENCH_BACKEND", "TSAR_BENCH_FORCE_DIST", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
+    else:
+        env.update({"TSAR_BENCH_BACKEND": backend, "MASTER_ADDR": "127.0.0.1"})
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
     env.update(env_extra or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -40,9 +49,12 @@ def _run_bench(world, extra, env_extra=None, timeout=600, backend="gloo"):
     return json.loads(lines[0])
 
 
-def test_bench_two_ranks_gather_is_bit_exact():
+@pytest.mark.parametrize("as_typed", [False, True])
+def test_bench_two_ranks_gather_is_bit_exact(as_typed):
+    """as_typed: `python bench.py --gpus 2 --steps 3 --warmup 1 ...` exactly as the driver types its N = 1 run — bench.py launches
+    the two ranks under torch.distributed.run itself and verifies the gather without being asked"""
     line = _run_bench(2, ["--steps", "3", "--warmup", "1", "--width", "640", "--height", "480", "--views", "4", "--iters", "2",
-                          "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing"])
+                          "--no-cpu-baseline", "--no-kernel-timing"] + ([] if as_typed else ["--verify-gather"]), as_typed=as_typed)
     assert line["gather_check"]["verified"] is True, line["gather_check"]
     assert line["gather_check"]["ranks_differ"] is True, line["gather_check"]     # each rank matched its own view
     assert line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
@@ -52,10 +64,11 @@ def test_bench_two_ranks_gather_is_bit_exact():
     assert line["config"]["frac_depth_within_1pct_of_gt"] > 0.5
 
 
-def test_bench_three_ranks_odd_step_count():
+@pytest.mark.parametrize("as_typed", [False, True])
+def test_bench_three_ranks_odd_step_count(as_typed):
     """an odd number of steps ends on the other buffer set; three ranks on the one device"""
     line = _run_bench(3, ["--steps", "2", "--warmup", "0", "--width", "320", "--height", "240", "--views", "3", "--iters", "1",
-                          "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing"])
+                          "--verify-gather", "--no-cpu-baseline", "--no-kernel-timing"], as_typed=as_typed)
     assert line["gather_check"]["verified"] is True and line["gather_check"]["ranks_differ"] is True
     assert len(line["gather_check"]["per_rank_depth_checksum"]) == 3
 

@@ -62,7 +62,10 @@ def main():
     gt = sc.gt_depth
     scale = ((depth - gt).abs() / gt < 0.01).float().cpu().numpy()
     timed(rows, "set_reliable_mask (H2D)", lambda: m.set_reliable_mask(scale), bytes_moved=np_ * 4)
-    labels, text, size = timed(rows, "detect_weak_texture (pyrDown x2, Roberts, CCL, stats; D2H labels)", m.detect_weak_texture)
+    # two rows: what the CLI pays (labels_out = NULL: the labels stay on the device for RANSAC / fill, host/tsar_gipuma.cpp) and the
+    # same call when a caller also wants the [h][w] int32 label map on the host (98 MB into pageable memory at 24 MP: a copy, not a kernel)
+    timed(rows, "detect_weak_texture, labels_out = NULL (what tsar_gipuma calls: pyrDown x2, Roberts, CCL, stats)", lambda: m.detect_weak_texture(want_labels=False))
+    labels, text, size = timed(rows, f"detect_weak_texture + {np_ * 4 / 1e6:.0f} MB label D2H to pageable host memory", m.detect_weak_texture)
     print(json.dumps({"regions": int(len(text)), "weak_regions": int((text == -1).sum()), "largest_weak_px": float(size[text == -1].max()) if (text == -1).any() else 0}))
     planes, ratio = timed(rows, "ransac_regions (first call: loads the rocPRIM code objects)", m.ransac_regions)
     t_first = dict(m.kernel_timing())

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "tsar_load_planes", "tsar_compute_disp", "tsar_compute_disp_final", "tsar_depth_to_plane", "tsar_get_result",
     "tsar_set_reliable_mask", "tsar_get_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
-    "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse",
+    "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse", "tsar_fuse_ctx",
     "tsar_host_alloc", "tsar_host_free", "tsar_device_alloc", "tsar_device_free", "tsar_device_write", "tsar_peer_copy", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
     "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sweep_census",
 ]
@@ -133,6 +133,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_default_fusion_params.argtypes = [C.POINTER(FusionParams)]
     L.tsar_fuse.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Camera), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int,
                             C.c_void_p, C.c_void_p, C.POINTER(FusionParams), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.tsar_fuse_ctx.argtypes = [C.c_void_p] + list(L.tsar_fuse.argtypes[1:])
     L.tsar_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.tsar_synchronize.argtypes = [C.c_void_p]
     L.tsar_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -376,13 +377,15 @@ class Matcher:
             self._chk(self.L.tsar_set_regions(self._ctx, _ptr(lb)[0], len(tx), _ptr(tx)[0], _ptr(sz)[0], MEM_HOST))
         self.n_regions = len(tx)
 
-    def detect_weak_texture(self, cap: int = 1 << 16):
-        """-> (labels [h, w] int32, region_text [n], region_size [n]); also installs them as the regions"""
-        labels = np.empty((self.h, self.w), np.int32)
+    def detect_weak_texture(self, cap: int = 1 << 16, want_labels: bool = True):
+        """-> (labels [h, w] int32, region_text [n], region_size [n]); also installs them as the regions.
+        want_labels=False: labels_out = NULL, the call tsar_gipuma makes (the labels stay on the device for the next operators;
+        no [h, w] int32 D2H copy) -> labels is None"""
+        labels = np.empty((self.h, self.w), np.int32) if want_labels else None
         text = np.empty(cap, np.float32)
         size = np.empty(cap, np.float32)
         n = C.c_int(0)
-        self._chk(self.L.tsar_detect_weak_texture(self._ctx, _ptr(labels)[0], MEM_HOST, C.byref(n), _ptr(text)[0], _ptr(size)[0], cap))
+        self._chk(self.L.tsar_detect_weak_texture(self._ctx, _ptr(labels)[0] if want_labels else None, MEM_HOST, C.byref(n), _ptr(text)[0], _ptr(size)[0], cap))
         self.n_regions = n.value
         k = min(n.value, cap)
         return labels, text[:k].copy(), size[:k].copy()
@@ -449,8 +452,9 @@ def matcher_from_scene(scene, box=11, n_best=1, cost_comb=COMB_BEST_N, flags=0, 
     return m
 
 
-def fuse(depths, normals, grays, K, R, t, pairs, params: FusionParams | None = None, cap: int | None = None, device: int = 0):
-    """Fuse per-view depth [h, w] / world-normal [h, w, 3] maps into a point cloud (tsar_fuse).
+def fuse(depths, normals, grays, K, R, t, pairs, params: FusionParams | None = None, cap: int | None = None, device: int = 0, matcher=None):
+    """Fuse per-view depth [h, w] / world-normal [h, w, 3] maps into a point cloud (tsar_fuse; with `matcher`, tsar_fuse_ctx on that
+    context: its stream, temporaries from its scratch arena).
     pairs: {view: [source views]} or list of lists.  Returns an [n, 9] float32 array:
     x y z, nx ny nz, gray, number of agreeing views, reference view."""
     L = load_library()
@@ -486,10 +490,11 @@ def fuse(depths, normals, grays, K, R, t, pairs, params: FusionParams | None = N
         cap = n * h * w
     out = np.empty((cap, 9), np.float32)
     cnt = C.c_int64(0)
-    rc = L.tsar_fuse(device, n, w, h, cams, pd, pn, pg, kinds.pop(), off.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), C.byref(params),
-                     out.ctypes.data_as(C.c_void_p), cap, C.byref(cnt))
+    tail = (n, w, h, cams, pd, pn, pg, kinds.pop(), off.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), C.byref(params),
+            out.ctypes.data_as(C.c_void_p), cap, C.byref(cnt))
+    rc = L.tsar_fuse_ctx(matcher._ctx, *tail) if matcher is not None else L.tsar_fuse(device, *tail)
     if rc != TSAR_OK:
-        raise TsarError(rc, "tsar_fuse failed")
+        raise TsarError(rc, L.tsar_last_error(matcher._ctx).decode() if matcher is not None else "tsar_fuse failed")
     return out[: min(cnt.value, cap)].copy()
 
 

@@ -101,18 +101,28 @@ __global__ __launch_bounds__(FU_BLOCK) void fuse_view_kernel(int view, int w, in
             if (used_bits >> k & 1ull) pending[(size_t)src[k] * np + (size_t)used_q[k]] = 1;
 }
 
-extern "C" int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth, const float* const* normal_world,
-                         const float* const* gray, int mem, const int32_t* src_off, const int32_t* src_idx, const tsar_fusion_params* prm,
-                         float* points_out, int64_t cap, int64_t* n_points_out) {
-    if (n_views < 2 || w < 1 || h < 1 || !cams || !depth || !normal_world || !gray || !src_off || !src_idx || !prm || !n_points_out) return TSAR_ERR_INVALID;
-    if (mem != TSAR_MEM_DEVICE && mem != TSAR_MEM_HOST) return TSAR_ERR_INVALID;
-    if (hipSetDevice(device) != hipSuccess) return TSAR_ERR_HIP;
+// On a context: its stream, and every temporary (uploaded maps, marks, records, rocPRIM scratch) out of its scratch arena — a host
+// that fuses scene after scene (or the tests, call after call) allocates nothing from the second call on (tsar_dev.h ScratchScope).
+extern "C" int tsar_fuse_ctx(tsar_ctx* ctx, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth, const float* const* normal_world,
+                             const float* const* gray, int mem, const int32_t* src_off, const int32_t* src_idx, const tsar_fusion_params* prm,
+                             float* points_out, int64_t cap, int64_t* n_points_out) {
+    if (!ctx) return TSAR_ERR_INVALID;
+    auto bad = [&](const char* msg) { ctx->err = msg; return TSAR_ERR_INVALID; };
+    if (n_views < 2 || w < 1 || h < 1 || !cams || !depth || !normal_world || !gray || !src_off || !src_idx || !prm || !n_points_out) return bad("tsar_fuse: null argument, fewer than two views or an empty image");
+    if (mem != TSAR_MEM_DEVICE && mem != TSAR_MEM_HOST) return bad("tsar_fuse: mem must be TSAR_MEM_HOST or TSAR_MEM_DEVICE");
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return TSAR_ERR_HIP; }
     const size_t np = (size_t)w * h;
-    hipStream_t st;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return TSAR_ERR_HIP;
-    std::vector<void*> to_free;
-    auto dmalloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; to_free.push_back(p); return p; };
-    auto done = [&](int rc) { hipStreamSynchronize(st); for (void* p : to_free) hipFree(p); hipStreamDestroy(st); return rc; };
+    hipStream_t st = ctx->stream;
+    ScratchScope scratch(ctx);
+    auto dmalloc = [&](size_t bytes) -> void* { return scratch.alloc(bytes); };
+    auto done = [&](int rc) {
+        if (hipStreamSynchronize(st) != hipSuccess && rc == TSAR_OK) rc = TSAR_ERR_HIP;
+        scratch.release();
+        if (rc == TSAR_ERR_NOMEM) ctx->err = "tsar_fuse: device allocation failed";
+        else if (rc == TSAR_ERR_HIP) ctx->err = "tsar_fuse: HIP call failed";
+        else if (rc == TSAR_ERR_INVALID) ctx->err = "tsar_fuse: a view's maps are NULL or a source index is out of range";
+        return rc;
+    };
     // inputs
     std::vector<const float*> hd(n_views), hn(n_views), hg(n_views);
     for (int v = 0; v < n_views; v++) {
@@ -173,7 +183,19 @@ extern "C" int tsar_fuse(int device, int n_views, int w, int h, const tsar_camer
         }
     }
     *n_points_out = n_out;
-    return done(hipStreamSynchronize(st) == hipSuccess ? TSAR_OK : TSAR_ERR_HIP);
+    return done(TSAR_OK);
+}
+
+// Context-free form (the fuser binary's one call per scene): a context of its own for the duration of the call.
+extern "C" int tsar_fuse(int device, int n_views, int w, int h, const tsar_camera* cams, const float* const* depth, const float* const* normal_world,
+                         const float* const* gray, int mem, const int32_t* src_off, const int32_t* src_idx, const tsar_fusion_params* prm,
+                         float* points_out, int64_t cap, int64_t* n_points_out) {
+    tsar_ctx* ctx = nullptr;
+    const int rc0 = tsar_create(device, &ctx);
+    if (rc0 != TSAR_OK) return rc0;
+    const int rc = tsar_fuse_ctx(ctx, n_views, w, h, cams, depth, normal_world, gray, mem, src_off, src_idx, prm, points_out, cap, n_points_out);
+    tsar_destroy(ctx);
+    return rc;
 }
 
 extern "C" void tsar_default_fusion_params(tsar_fusion_params* p) {   // x/1.sh:20-25

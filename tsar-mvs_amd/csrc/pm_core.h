@@ -1,5 +1,5 @@
 // pm_core.h — the matching cost and the per-pixel PatchMatch step, shared by the init / sweep /
-// cost-evaluation kernels (pm_init.hip, pm_sweep.hip, pm_sweep_lds.hip).
+// cost-evaluation kernels (pm_init.hip, pm_sweep.hip).
 //
 // Mapping (MI355X-first): one thread owns one pixel and walks its hypotheses; a
 // 256-thread workgroup owns a 32-wide pixel region.  Per workgroup, once per launch:
@@ -80,8 +80,6 @@ template <bool QUAD> struct TileOf { typedef float type; };
 template <> struct TileOf<true> { typedef unsigned short type; };     // upper half of the fp32 pattern: exact for 0..255
 DEVFN float tile_value(float t) { return t; }
 DEVFN float tile_value(unsigned short t) { return __uint_as_float((uint32_t)t << 16); }
-DEVFN float tile_value(unsigned char t) { return (float)t; }               // pm_sweep_lds.hip keeps a byte window
-DEVFN void tile_store(unsigned char* t, float v) { *t = (unsigned char)v; }
 DEVFN void tile_store(float* t, float v) { *t = v; }
 DEVFN void tile_store(unsigned short* t, float v) { *t = (unsigned short)(__float_as_uint(v) >> 16); }
 template <bool QUAD>
@@ -213,6 +211,8 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
         else if constexpr (QUAD && HR == 5 && r5_production_variant(V))
             c = view_cost_r5<STRICT, (V & 128) != 0 && !STRICT, (V & 8) != 0, (V & 131072) != 0, (V & 2097152) != 0, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
 #ifdef TSAR_EXPERIMENTS
+        else if constexpr (QUAD && HR == 5 && r5_diag_variant(V))
+            c = view_cost_r5<false, true, true, true, true, BLK, (V & 4194304) ? 1 : 2>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         else if constexpr (V != 0) c = view_cost_variants<HR, STRICT, QUAD, V, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
 #endif
         else {

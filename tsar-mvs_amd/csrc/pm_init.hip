@@ -23,7 +23,7 @@ static int launch_full(tsar_ctx* ctx, const float4* planes, float* c, float4* n,
     const DevScene& hs = ctx->hscene;
     const int need = hs.cost_comb == TSAR_COMB_BEST_N ? (hs.n_best < hs.n_sel ? hs.n_best : hs.n_sel) : hs.n_sel;
     const bool r5 = hs.hrad == 5 && hs.vrad == 5;
-    if (lut_path_applies(ctx) && (!(r5 && need <= 2) || (hs.flags & TSAR_FLAG_TEX_FILTER_8BIT) || lut_path_forced())) return launch_pm_full_lut(ctx, need, INIT, planes, c, n, bv, rt);   // pm_init_lut.hip
+    if (lut_path_applies(ctx) && (!(r5 && need <= 2) || (hs.flags & TSAR_FLAG_TEX_FILTER_8BIT) || lut_path_forced(ctx))) return launch_pm_full_lut(ctx, need, INIT, planes, c, n, bv, rt);   // pm_init_lut.hip
     if (need <= 2) return r5 ? launch_full_nh<2, 5, INIT>(ctx, planes, c, n, bv, rt) : launch_full_nh<2, 0, INIT>(ctx, planes, c, n, bv, rt);
     return r5 ? launch_full_nh<32, 5, INIT>(ctx, planes, c, n, bv, rt) : launch_full_nh<32, 0, INIT>(ctx, planes, c, n, bv, rt);
 }

@@ -55,7 +55,7 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
             // small images: 128-thread workgroups (see SWEEP_SMALL_IMAGE_TILES); TSAR_BLOCK=128|256 forces a shape (A/B runs)
             const int tiles256 = ((ctx->hscene.w + PM_RW - 1) / PM_RW) * ((ctx->hscene.h + 15) / 16);
             bool small = tiles256 < SWEEP_SMALL_IMAGE_TILES;
-            if (const char* e = getenv("TSAR_BLOCK")) small = atoi(e) == 128;
+            if (ctx->force_block) small = ctx->force_block == 128;
             if (small && v != 114) {
                 if (strict) return SWEEP_R5(true, 122, 128);
                 return v == 250 ? SWEEP_R5_FAST250(128) : launch_sweep_t<2, 5, false, true, 122, 128>(ctx, colour, a, b, c, sid, dp, dr);
@@ -76,7 +76,7 @@ int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const Pl
                     int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
 #ifdef TSAR_EXPERIMENTS
-    {   // measured-and-rejected / diagnostic forms (pm_sweep_experiments.hip: TSAR_VARIANT; pm_sweep_lds.hip: TSAR_LDS_SWEEP=1)
+    {   // measured-and-rejected / diagnostic forms (pm_sweep_experiments.hip: TSAR_VARIANT / TSAR_VARIANT_NOW)
         int launched = 0;
         const int rc = launch_pm_sweep_experiment(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine, &launched);
         if (rc != TSAR_OK || launched) return rc;
@@ -88,7 +88,7 @@ int launch_pm_sweep(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const Pl
     // table, chunked lines (pm_sweep_lut.hip)
     // (the box-11 loop filters with exact fp32 weights only: the 8-bit filter mode takes the general-window loop at box 11 too)
     const bool own_loop = r5 && need <= 4 && (need <= 2 || ctx->variant == 250 || ctx->variant == 122) && !(hs.flags & TSAR_FLAG_TEX_FILTER_8BIT);   // (TSAR_VARIANT=0 or an experiment: the generic loop below)
-    if (lut_path_applies(ctx) && (!own_loop || lut_path_forced())) return launch_pm_sweep_lut(ctx, need, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
+    if (lut_path_applies(ctx) && (!own_loop || lut_path_forced(ctx))) return launch_pm_sweep_lut(ctx, need, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     if (need <= 4 && need > 2 && r5) return launch_sweep_nh<4, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);
     if (need <= 2) return r5 ? launch_sweep_nh<2, 5>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine)
                              : launch_sweep_nh<2, 0>(ctx, colour, same_in, other, same_out, stream_id, do_prop, do_refine);

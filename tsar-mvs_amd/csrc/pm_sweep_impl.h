@@ -241,7 +241,11 @@ static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, co
     constexpr int SWEEP_RH = 2 * BLK / RW;
     const int tiles_x = (hs.w + RW - 1) / RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
     const int n_tiles = tiles_x * tiles_y;
-    static const size_t lds_pad = getenv("TSAR_LDS_PAD") ? (size_t)atoi(getenv("TSAR_LDS_PAD")) : 0;   // occupancy experiments: unused LDS per workgroup
+#ifdef TSAR_EXPERIMENTS
+    const size_t lds_pad = ctx->lds_pad;       // occupancy experiments: unused LDS per workgroup
+#else
+    constexpr size_t lds_pad = 0;
+#endif
     const size_t lds = tile_bytes<QUAD>(RW + 2 * hs.hrad, SWEEP_RH + 2 * hs.vrad + ((V & 1024) ? LUT_TILE_PAD_ROWS : 0)) + lds_pad +
                        ((V & 1024) ? (size_t)(hs.lut_classes + 1) * 1024 : sizeof(float) * (size_t)(hs.hrad + 1) * (hs.vrad + 1) * BLK);
     auto kern = pm_sweep_kernel<NB, HR, STRICT, QUAD, V, BLK>;

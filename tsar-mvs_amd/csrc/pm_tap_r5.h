@@ -32,7 +32,10 @@
 // BLK: threads per workgroup = stride, in floats, between the weights of consecutive taps of one thread ([tap][thread]).
 #pragma once
 
-template <bool STRICT, bool ROW, bool D16, bool BUF, bool MIX, int BLK>
+// DIAG (experiments build only, WRONG RESULTS by construction; the ceilings of profiles/r04): 1 = the MIX body with every gather
+// removed (the tap's halfs are synthesised from its element index: the VALU floor of the shipping body), 2 = every gather replaced
+// by an 8-byte LDS read at a per-lane address (ds_read_b64: the instruction mix of source patches staged in LDS, before any staging).
+template <bool STRICT, bool ROW, bool D16, bool BUF, bool MIX, int BLK, int DIAG = 0>
 DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, const unsigned short* tile, int tw, int own, const float* wts,
                          const PixelRef& pr, int x, int y, const float4& n4) {
     static_assert(!(STRICT && ROW), "the row-wise walk changes the summation order: fast mode only");
@@ -169,7 +172,13 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             // element index of quad entry (iv + 1, iu + 1) from entry (1, 1): one 24-bit multiply-add
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
-            if (MIX) {
+            if (MIX && DIAG == 1) {
+                q2[jj] = ((uint64_t)(uint32_t)lin << 32) | (uint32_t)lin;
+            } else if (MIX && DIAG == 2) {
+                uint32_t la;                                    // inside the workgroup's first 32 KiB of LDS, lanes 16 bytes apart like a staged patch
+                asm("v_bfe_u32 %0, %1, 0, 12" : "=v"(la) : "v"(lin));
+                asm volatile("ds_read_b64 %0, %1" : "=v"(q2[jj]) : "v"(la << 3));
+            } else if (MIX) {
                 asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 idxen" : "=v"(q2[jj]) : "v"(lin), "s"(rsrc));
             } else if (BUF) {
                 asm volatile("buffer_load_dword %0, %1, %2, 0 idxen" : "=v"(q[jj]) : "v"(lin), "s"(rsrc));
@@ -184,7 +193,12 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 3: unpack, blend, accumulate
             float t00, t10, t01, t11;                           // the four texels: one convert each, no shifts/masks
-            if (MIX) {
+            if (MIX && DIAG == 1) {
+            } else if (MIX && DIAG == 2) {                      // LDS returns in order: tap jj has 5 - jj reads behind it
+                if (jj == 0) asm("s_waitcnt lgkmcnt(5)" : "+v"(q2[0]), "+v"(rcol[0]), "+v"(rcol[1]), "+v"(rcol[2]), "+v"(rcol[3]), "+v"(rcol[4]), "+v"(rcol[5]),
+                                 "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]) : "v"(q2[5]));
+                else asm("s_waitcnt lgkmcnt(%2)" : "+v"(q2[jj]), "+v"(sum_src_src) : "n"(5 - jj), "v"(q2[5]));
+            } else if (MIX) {
                 if (jj == 0) asm("s_waitcnt vmcnt(5)" : "+v"(q2[0]) : "v"(q2[5]));
                 if (jj == 1) asm("s_waitcnt vmcnt(4)" : "+v"(q2[1]), "+v"(sum_src_src) : "v"(q2[5]));
                 if (jj == 2) asm("s_waitcnt vmcnt(3)" : "+v"(q2[2]), "+v"(sum_src_src) : "v"(q2[5]));
@@ -228,7 +242,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             }
             // one wait per line, at its first tap: every LDS load of the line (six texels when they are D16 loads, three weight
             // pairs) was issued before the gathers, in order, and has long returned when the first gather does
-            if (jj == 0) {
+            if (jj == 0 && DIAG != 2) {
                 if (D16)
                     asm("s_waitcnt lgkmcnt(0)" : "+v"(rcol[0]), "+v"(rcol[1]), "+v"(rcol[2]), "+v"(rcol[3]), "+v"(rcol[4]), "+v"(rcol[5]),
                         "+v"(wcol[0]), "+v"(wcol[1]), "+v"(wcol[2]), "+v"(s));
@@ -263,4 +277,6 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
 
 // The variant numbers the production kernels are instantiated with (and which profiles name): bits 1, 4, 5, 6 always set.
 // + 2097152 (with 250 | 131072): MIX
+// + 4194304 / + 8388608 (experiments build): DIAG 1 / 2 of the MIX body
+__host__ __device__ constexpr bool r5_diag_variant(int V) { return V == (250 | 131072 | 2097152 | 4194304) || V == (250 | 131072 | 2097152 | 8388608); }
 __host__ __device__ constexpr bool r5_production_variant(int V) { return V == 114 || V == 122 || V == 250 || V == (114 | 131072) || V == (122 | 131072) || V == (250 | 131072) || V == (250 | 131072 | 2097152); }

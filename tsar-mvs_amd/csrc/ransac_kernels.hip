@@ -557,7 +557,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
     const int nreg = ctx->n_regions;
     const size_t np = (size_t)ctx->w * ctx->h;
     hipStream_t st = ctx->stream;
-    static const bool trace = getenv("TSAR_TRACE_HOST") != nullptr;
+    const bool trace = ctx->trace_host;
     auto tr0 = std::chrono::steady_clock::now();
     auto TR = [&](const char* what) { if (trace) { hipStreamSynchronize(st); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[ransac] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tr0).count()); tr0 = n; } };
     std::vector<float> text(nreg);
@@ -651,10 +651,10 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
         // stage 2, measured on six ~50 000-point regions: the history tree with lookahead 1 / 2 / 3 -> 25.9 / 26.4 / 33.7 ms (the passes
         // are bound by the CU's FP64 rate, so the extra planes of a tree cost what the saved passes return); the speculative chain of
         // 8 steps 17.5 ms; the chain on 8 CUs per region 5.3 ms (the default).
-        const int lookahead = getenv("TSAR_RANSAC_LOOKAHEAD") ? atoi(getenv("TSAR_RANSAC_LOOKAHEAD")) : 0;
+        const int lookahead = ctx->ransac_lookahead;
         // default: the speculative chain (ransac_refine_chain_kernel), K = 8; TSAR_RANSAC_CHAIN=4|8|16 picks the length,
         // TSAR_RANSAC_LOOKAHEAD=1|2|3 the history-tree kernel instead
-        const int chain = getenv("TSAR_RANSAC_CHAIN") ? atoi(getenv("TSAR_RANSAC_CHAIN")) : 8;
+        const int chain = ctx->ransac_chain;
         {
             ScopedKernelTimer tm(ctx, "ransac_fit");
             for (int phase = 0; phase < 10; phase++) {
@@ -668,7 +668,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
             // W workgroups (CUs) per region in stage 2 (ransac_refine_chain_mw_kernel): 8 by default (measured on five ~50 000-point
             // regions: W = 1 / 2 / 4 / 8 / 16 -> 17.5 / 10.8 / 6.9 / 5.3 / 4.8 ms for the whole fit), at most one workgroup per CU so
             // that all of them are resident together; TSAR_RANSAC_WGS=W overrides, 1 = the single-workgroup kernel
-            int wgs = getenv("TSAR_RANSAC_WGS") ? atoi(getenv("TSAR_RANSAC_WGS")) : 8;
+            int wgs = ctx->ransac_wgs;
             int n_cu = 0;
             if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) n_cu = 0;
             if (wgs > n_cu / (nslot > 0 ? nslot : 1)) wgs = n_cu / (nslot > 0 ? nslot : 1);
@@ -681,8 +681,8 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                 // diagnostics: TSAR_RANSAC_FORCE_FALLBACK=1 pre-sets `failed` (the give-up path: every workgroup leaves, the
                 // single-workgroup kernel below produces the result); TSAR_RANSAC_POLL_LIMIT=n bounds a wait (default 2^15 polls
                 // of ~0.3 us: ~10 ms, three orders of magnitude above a pass)
-                const bool force_fallback = getenv("TSAR_RANSAC_FORCE_FALLBACK") && getenv("TSAR_RANSAC_FORCE_FALLBACK")[0] == '1';
-                int poll_limit = getenv("TSAR_RANSAC_POLL_LIMIT") ? atoi(getenv("TSAR_RANSAC_POLL_LIMIT")) : (1 << 15);
+                const bool force_fallback = ctx->ransac_force_fallback;
+                int poll_limit = ctx->ransac_poll_limit;
                 if (force_fallback) { const int one = 1; hipMemcpyAsync(d_failed, &one, 4, hipMemcpyHostToDevice, st); }
                 const void* mw = chain == 4 ? (const void*)ransac_refine_chain_mw_kernel<4> : (chain == 16 ? (const void*)ransac_refine_chain_mw_kernel<16> : (const void*)ransac_refine_chain_mw_kernel<8>);
                 const float* a_pts = d_pts; const int *a_ps = d_pts_start, *a_pc = d_pts_count, *a_rs = d_region_of_slot, *a_cnt = d_cnt;
@@ -694,7 +694,7 @@ extern "C" int tsar_ransac_regions(tsar_ctx* ctx, float* region_planes_out, floa
                 void* args[] = {&a_pts, &a_ps, &a_pc, &a_rs, &a_k0, &a_k1, &a_fl, &a_state, &a_cnt, &a_n4, &a_ratio, &a_w, &d_sync, &d_failed, &poll_limit};
                 int coop = 0;
                 if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device) != hipSuccess) coop = 0;
-                if (getenv("TSAR_RANSAC_COOPERATIVE") && getenv("TSAR_RANSAC_COOPERATIVE")[0] == '0') coop = 0;
+                if (!ctx->ransac_cooperative) coop = 0;
                 // One cooperative grid at a time per process: the contexts of one process (tsar_gipuma --workers=2, ranks' threads) would
                 // otherwise compete for the CUs their grids must hold together — and two threads inside hipLaunchCooperativeKernel at
                 // once leave the runtime (ROCm 7.2) in a state that crashes at process exit (seen in the two-contexts test).  The lock

@@ -292,7 +292,7 @@ extern "C" int tsar_detect_weak_texture(tsar_ctx* ctx, int32_t* labels_out, int 
     if (w4 < 3 || h4 < 3) { ctx->err = "image too small for weak-texture detection"; return TSAR_ERR_INVALID; }
     const int n4 = w4 * h4;
     hipStream_t st = ctx->stream;
-    static const bool trace = getenv("TSAR_TRACE_HOST") != nullptr;     // host-side steps on stderr (diagnostics)
+    const bool trace = ctx->trace_host;     // host-side steps on stderr (diagnostics)
     auto tr0 = std::chrono::steady_clock::now();
     auto TR = [&](const char* what) { if (trace) { hipStreamSynchronize(st); auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[weak_texture] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - tr0).count()); tr0 = n; } };
     ScratchScope scratch(ctx);           // temporaries come out of the context's arena (tsar_dev.h)

@@ -234,6 +234,29 @@ extern "C" const char* tsar_version(void) {
 #endif
 }
 
+// Every environment knob of the library, read once per context.  All are diagnostics / A-B switches: the defaults
+// are the measured best and nothing in the product path depends on one being set.
+static void read_knobs(tsar_ctx* ctx) {
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && e[0] ? atoi(e) : dflt; };
+    auto on = [](const char* name, bool dflt) { const char* e = getenv(name); return e && e[0] ? e[0] != '0' : dflt; };
+    ctx->variant = num("TSAR_VARIANT", ctx->variant);
+    ctx->buffer_gather = on("TSAR_BUFFER_GATHER", true);
+    ctx->mix_gather = on("TSAR_MIX_GATHER", true);
+    ctx->strip_w = num("TSAR_STRIP", -1);
+    ctx->force_block = num("TSAR_BLOCK", 0);
+    ctx->lut_mode = num("TSAR_LUT", 1);
+    ctx->ransac_wgs = num("TSAR_RANSAC_WGS", 8);
+    ctx->ransac_chain = num("TSAR_RANSAC_CHAIN", 8);
+    ctx->ransac_lookahead = num("TSAR_RANSAC_LOOKAHEAD", 0);
+    ctx->ransac_poll_limit = num("TSAR_RANSAC_POLL_LIMIT", 1 << 15);
+    ctx->ransac_cooperative = on("TSAR_RANSAC_COOPERATIVE", true);
+    ctx->ransac_force_fallback = on("TSAR_RANSAC_FORCE_FALLBACK", false);
+    ctx->trace_host = getenv("TSAR_TRACE_HOST") != nullptr;
+#ifdef TSAR_EXPERIMENTS
+    ctx->lds_pad = (size_t)num("TSAR_LDS_PAD", 0);
+#endif
+}
+
 extern "C" int tsar_create(int device, tsar_ctx** out) {
     if (!out) return TSAR_ERR_INVALID;
     *out = nullptr;
@@ -246,16 +269,8 @@ extern "C" int tsar_create(int device, tsar_ctx** out) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return TSAR_ERR_HIP; }
     tsar_default_params(&ctx->params);
-#ifdef TSAR_EXPERIMENTS
-    if (const char* e = getenv("TSAR_LDS_SWEEP")) ctx->lds_sweep = e[0] == '1';
-#endif
     ctx->variant = probe_d16_hi_zeroes(ctx) ? 250 : 114;
-    if (const char* e = getenv("TSAR_VARIANT")) ctx->variant = atoi(e);
-    if (const char* e = getenv("TSAR_BUFFER_GATHER")) ctx->buffer_gather = e[0] != '0';
-    if (const char* e = getenv("TSAR_MIX_GATHER")) ctx->mix_gather = e[0] != '0';
-    if (const char* e = getenv("TSAR_STRIP")) ctx->strip_w = atoi(e);
-    if (const char* e = getenv("TSAR_DEBUG_COUNTERS"))
-        if (e[0] == '1' && hipMalloc((void**)&ctx->dbg, 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(ctx->dbg, 0, 8 * sizeof(unsigned long long));
+    read_knobs(ctx);
     *out = ctx;
     return TSAR_OK;
 }
@@ -279,12 +294,6 @@ extern "C" int tsar_destroy(tsar_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
-    if (ctx->dbg) {
-        unsigned long long h[8] = {0};
-        hipMemcpy(h, ctx->dbg, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[tsar counters] lds-path wave evaluations %llu, gather-path %llu, vetoing lanes %llu\n", h[0], h[1], h[2]);
-        hipFree(ctx->dbg);
-    }
     free_views(ctx);
     free_planes(ctx);
     dev_free(ctx->dscene); dev_free(ctx->region_text); dev_free(ctx->region_size); dev_free(ctx->region_n4);
@@ -339,9 +348,32 @@ extern "C" int tsar_set_params(tsar_ctx* ctx, const tsar_params* p) {
     return TSAR_OK;
 }
 
+// Strict mode's quotients are bit-exact because persp_divide_exact / div_pair_rcp_exact (tsar_device_math.h) return the correctly
+// rounded quotient — a property of THIS GPU's v_rcp_f32, enumerated over all 2^46 mantissa pairs on the device it was measured on
+// (profiles/r03/div_exact_all_mantissa_pairs.json).  Like the D16 probe, it is re-checked where it is relied on: once per context,
+// before the first strict-mode views are accepted, 2^22 random operand triples in each of the tap loop's two operand
+// distributions through the SHIPPED unguarded code path against the compiler's IEEE division (~1 ms).  A device whose reciprocal
+// differs fails loudly here instead of drifting from the oracle silently.
+static int probe_exact_divide(tsar_ctx* ctx) {
+    if (ctx->exact_div_probe != 0) return ctx->exact_div_probe;
+    uint64_t bad = 0, total = 0;
+    for (int mode = 0; mode < 2; mode++) {
+        if (tsar_selftest_divide_random(ctx, 22, 0x5EEDD1F1DE5ull + (uint64_t)mode, mode, /*guarded=*/0, &bad, nullptr) != TSAR_OK) return 0;   // not probed: the caller reports ctx->err
+        total += bad;
+    }
+    ctx->exact_div_probe = total == 0 ? 1 : -1;
+    return ctx->exact_div_probe;
+}
+
 extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
     CHECK_CTX(ctx);
     if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
+    if (ctx->params.flags & TSAR_FLAG_STRICT_DIV) {
+        const int pr = probe_exact_divide(ctx);
+        if (pr == 0) return TSAR_ERR_HIP;
+        if (pr < 0) return fail(ctx, TSAR_ERR_HIP, "TSAR_FLAG_STRICT_DIV: this device's v_rcp_f32 does not give correctly rounded quotients through the short division "
+                                                   "sequence (tsar_selftest_divide_random found mismatches against IEEE division); strict mode is refused rather than run inexactly");
+    }
     if (n_views < 1 || n_views > TSAR_MAX_VIEWS) return fail(ctx, TSAR_ERR_INVALID, "n_views must be in 1..TSAR_MAX_VIEWS");
     if (w < 8 || h < 8 || (int64_t)w * h > (int64_t)1 << 28) return fail(ctx, TSAR_ERR_INVALID, "image size out of range");
     if (w + 2 >= (1 << 23) || h + 2 >= (1 << 23)) return fail(ctx, TSAR_ERR_INVALID, "image side too long for the 24-bit quad addressing (w + 2, h + 2 < 2^23)");
@@ -454,15 +486,19 @@ extern "C" int tsar_pm_init(tsar_ctx* ctx) {
     NEED_VIEWS(ctx);
     NEED_SOURCES(ctx);
     const bool own_window = init_window_differs(ctx);
+    int rc = TSAR_OK;
     if (own_window) {                      // an even box: the scene block describes the init window for this one launch
         fill_scene_params(ctx, true);
-        TRY(upload_scene(ctx));
+        rc = upload_scene(ctx);
     }
-    int rc = launch_pm_init(ctx);
+    if (rc == TSAR_OK) rc = launch_pm_init(ctx);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
     if (own_window) {
+        // back to the sweep window on EVERY path (also when the first upload failed: the host block was already rewritten); if the
+        // device block cannot be restored, host and device disagree about the window and the views must be set again
         fill_scene_params(ctx, false);
         const int rc2 = upload_scene(ctx);
+        if (rc2 != TSAR_OK) ctx->have_views = false;
         if (rc == TSAR_OK) rc = rc2;
     }
     TRY(rc);

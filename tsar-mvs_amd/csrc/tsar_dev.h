@@ -115,16 +115,29 @@ struct tsar_ctx {
     int n_regions = 0;
     float *region_text = nullptr, *region_size = nullptr;
     float4* region_n4 = nullptr;
+    int exact_div_probe = 0;     // strict mode's short exact division on THIS device: 0 not probed yet, 1 holds, -1 failed (probe_exact_divide)
     int sweeps_done = 0;         // RNG stream counter
     const float* final_text = nullptr;   // device lines->text while tsar_pm_iterate_final runs (the kernels' `final` mode), else null
     // timing
-    bool lds_sweep = false;      // TSAR_LDS_SWEEP=1: LDS-patch form of the sweep (pm_sweep_lds.hip); bit-exact, not yet faster
     int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); tsar_create picks 250 (med3/fract + D16 window loads + clamp-free loop for in-image windows + wave priority + SGPR-pinned texture base and line-top weight loads + row-wise window walk in fast mode; strict mode runs it as 122, the oracle's column order) when the D16 probe passes, else 114
     bool mix_gather = true;      // TSAR_MIX_GATHER=0: keep the byte texture for the buffer-load launches too (pm_tap_r5.h MIX off)
     bool buffer_gather = true;   // TSAR_BUFFER_GATHER=0: the fast tap loop's gathers as global loads + a shift instead of structured buffer loads
     int strip_w = -1;            // TSAR_STRIP=n: width in tiles of the strips the sweep walks (pm_core.h strip_tile), 0 = row-major,
                                  // -1 = automatic: one vertical band of the image per XCD (see strip_width)
-    unsigned long long* dbg = nullptr;   // TSAR_DEBUG_COUNTERS=1: device counters printed by tsar_destroy
+    // The remaining environment knobs (DESIGN.md §4 lists them all).  Everything is read ONCE, by tsar_create (tsar_api.hip
+    // read_knobs): a context never looks at the environment again, and no knob is latched in a function-local static.
+    int force_block = 0;         // TSAR_BLOCK=128|256: force the sweep's workgroup shape (0: by image size, SWEEP_SMALL_IMAGE_TILES)
+    int lut_mode = 1;            // TSAR_LUT=0: one-tap loop for windows other than box 11; 2: box 11 through the general-window loop too
+    int ransac_wgs = 8;          // TSAR_RANSAC_WGS: workgroups per region in RANSAC stage 2 (1 = the single-workgroup kernel)
+    int ransac_chain = 8;        // TSAR_RANSAC_CHAIN=4|8|16: speculative steps per pass
+    int ransac_lookahead = 0;    // TSAR_RANSAC_LOOKAHEAD=1|2|3: the history-tree kernel instead of the chain
+    int ransac_poll_limit = 1 << 15;      // TSAR_RANSAC_POLL_LIMIT: polls (~0.3 us each) before a stage-2 workgroup gives up waiting
+    bool ransac_cooperative = true;       // TSAR_RANSAC_COOPERATIVE=0: plain launch of the multi-workgroup stage 2
+    bool ransac_force_fallback = false;   // TSAR_RANSAC_FORCE_FALLBACK=1: pre-set the give-up flag (tests of that path)
+    bool trace_host = false;     // TSAR_TRACE_HOST=1: host-side steps of the refinement operators on stderr
+#ifdef TSAR_EXPERIMENTS
+    size_t lds_pad = 0;          // TSAR_LDS_PAD=n: unused LDS per sweep workgroup (occupancy experiments)
+#endif
     bool timing = false;
     std::vector<KernelTimer> timers;
     ScratchArena scratch;
@@ -198,12 +211,9 @@ int lut_chunk_taps(int taps_per_line);
 // the general-window tap loop serves 8-bit imagery (quad textures), both filter modes, whose window has few enough
 // distance classes for the LDS table; TSAR_LUT=0 switches it off (the one-tap-at-a-time loop then runs), TSAR_LUT=2 also sends
 // the box-11 / two-best-views configuration through it instead of its own tap loop: A/B measurements
-static inline bool lut_path_forced() {
-    static const bool forced = getenv("TSAR_LUT") && getenv("TSAR_LUT")[0] == '2';
-    return forced;
-}
+static inline bool lut_path_forced(const tsar_ctx* ctx) { return ctx->lut_mode == 2; }
 static inline bool lut_path_applies(const tsar_ctx* ctx) {
-    static const bool off = getenv("TSAR_LUT") && getenv("TSAR_LUT")[0] == '0';
+    const bool off = ctx->lut_mode == 0;
     const DevScene& hs = ctx->hscene;
     // (its fast-mode loop loads window texels with ds_read_u16_d16_hi: only where tsar_create's probe found the register's
     // other half zeroed — variant bit 3)
@@ -212,8 +222,6 @@ static inline bool lut_path_applies(const tsar_ctx* ctx) {
 }
 int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
                                int do_prop, int do_refine, int* launched);   // pm_sweep_experiments.hip (TSAR_EXPERIMENTS builds)
-int launch_pm_sweep_lds(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out, uint32_t stream_id,
-                        int do_prop, int do_refine, int* launched);
 int launch_pm_cost_planes(tsar_ctx* ctx, const float4* planes, float* cost, int32_t* beview, float* ratio);
 int launch_get_disp(tsar_ctx* ctx, const float* depth_in, const float* normal_world);
 int launch_compute_disp(tsar_ctx* ctx);
