@@ -57,8 +57,10 @@
  *       replication), so the oracle's bilinear() serves both;
  *   (5) ORC_FLAG_ROW_ORDER: the three source sums run over the window row by row (x fastest) instead of column by column
  *       (what the 8-bit-imagery kernels do; float imagery keeps columns);
- *   (6) the bilinear blend as t00 + ax d1 + ay d2 + (ax ay) d3 over texel differences (bilinear_qd) instead of two
- *       horizontal interpolations and a vertical one.
+ *   (6) the bilinear blend as (t00 + ax d1) + ay (d2 + ax d3) over the texel differences d1 = t10 - t00, d2 = t01 - t00,
+ *       d3 = t11 - t10 - t01 + t00 (bilinear_qd): the reference's top-row interpolation as it stands, and "bottom row minus top row"
+ *       formed as ONE fused multiply-add on the differences where the reference interpolates the bottom row and subtracts
+ *       (gipuma's tex2D blend: three roundings there, one here).  Three FMAs per tap.
  * The strict mode (no flag) remains the restatement of the reference; this mode is pinned to it only through the tolerances
  * stated in tests/test_gpu_fast_mode.py. */
 #define ORC_FLAG_FAST_ARITH (1u << 7)
@@ -164,8 +166,8 @@ static inline float texel(const float *img, int w, int h, int x, int y) {
 /* tex2D<float>(tex, u+0.5, v+0.5) with linear filtering, clamp addressing (main.cpp:1215-1219) */
 static inline float bilinear_qd(const float *img, int w, int h, float u, float v, int q8, int diff);
 static inline float bilinear_q(const float *img, int w, int h, float u, float v, int q8) { return bilinear_qd(img, w, h, u, v, q8, 0); }
-/* diff (S7 (6), fast arithmetic only): the blend as t00 + ax d1 + ay d2 + (ax ay) d3 over the texel differences d1 = t10 - t00,
- * d2 = t01 - t00, d3 = (t11 - t01) - d1 (exact integers on 8-bit imagery), three chained FMAs */
+/* diff (S7 (6), fast arithmetic only): the blend as (t00 + ax d1) + ay (d2 + ax d3) over the texel differences d1 = t10 - t00,
+ * d2 = t01 - t00, d3 = (t11 - t01) - d1 (exact integers on 8-bit imagery), three FMAs */
 static inline float bilinear_qd(const float *img, int w, int h, float u, float v, int q8, int diff) {
     u = fminf(fmaxf(u, -1.0f), (float)w);
     v = fminf(fmaxf(v, -1.0f), (float)h);
@@ -177,7 +179,7 @@ static inline float bilinear_qd(const float *img, int w, int h, float u, float v
     float t01 = texel(img, w, h, x0, y0 + 1), t11 = texel(img, w, h, x0 + 1, y0 + 1);
     if (diff) {
         const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
-        return fmaf(ax * ay, d3, fmaf(ay, d2, fmaf(ax, d1, t00)));
+        return fmaf(ay, fmaf(ax, d3, d2), fmaf(ax, d1, t00));
     }
     float top = fmaf(ax, t10 - t00, t00);
     float bot = fmaf(ax, t11 - t01, t01);

@@ -115,3 +115,41 @@ def test_async_double_buffered_gather_world_size_2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[0] for r in res), res
+
+
+def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` typed without a launcher: bench.self_launch starts torch.distributed.run as a CHILD with the same
+    arguments (+ --verify-gather), rendezvous on 127.0.0.1, and — with fewer devices than ranks, as on this CPU container — the
+    gloo rehearsal transport; the parent touches no GPU.  (The launched ranks themselves are covered by tests/test_gpu_multirank.py.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("TSAR_BENCH_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+
+    class A:
+        gpus = 4
+    assert bench.self_launch(A()) == 7                       # the child's exit code is handed on
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--verify-gather"]
+    assert seen["env"]["TSAR_BENCH_BACKEND"] == "gloo"       # 0 devices < 4 ranks: rehearsal transport
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # enough devices: the RCCL backend stays (no TSAR_BENCH_BACKEND forced)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    bench.self_launch(A())
+    assert "TSAR_BENCH_BACKEND" not in seen["env"]

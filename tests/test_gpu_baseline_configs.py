@@ -176,6 +176,33 @@ def test_tap_loop_without_d16_loads_bit_exact(monkeypatch, variant):
 
 
 
+@pytest.mark.parametrize("skew_ref,skew_src", [(0.0, 1.7), (0.9, 0.0), (0.6, -1.2)])
+def test_skewed_intrinsics_take_the_full_homography_products(skew_ref, skew_src):
+    """plane_homography (tsar_device_math.h) skips the products with the structural zeros of K_src and K_ref^-1 when NO camera of the
+    scene has skew (DevScene.k_sparse) — every synthetic scene, and every MVSNet-format cam file.  A skewed K in the reference
+    camera, in a source camera, or in both must fall back to the reference's two full 3x3 products: same bits as the oracle in
+    strict mode, box-11 loop and general-window loop, and the fast mode's restated arithmetic too."""
+    sc = synth.make_scene(128, 96, 3, seed=17)
+    sc.K = sc.K.copy()
+    sc.K[0, 0, 1] = skew_ref
+    sc.K[2, 0, 1] = skew_src
+    for box in (11, 7):
+        orc = _oracle(sc, seed=29, box=box)
+        orc.pm_init()
+        orc.pm_iterate(2)
+        m = api.matcher_from_scene(sc, seed=29, box=box, flags=api.FLAG_STRICT_DIV)
+        m.pm_init()
+        m.pm_iterate(2)
+        _assert_state_equal(m, orc)
+        m.lrdiff()                # rlCost (tsar_refine.hip) builds the same homography
+        m.getview()
+        m.compute_disp()
+        orc.lrdiff_op()
+        orc.getview()
+        assert np.array_equal(m.get_result()["confid"], orc.confid)
+        m.close()
+
+
 @pytest.mark.parametrize("box,n_best,n_src", [(19, 2, 3), (7, 1, 3), (11, 1, 1), (11, 3, 5), (5, 1, 2), (9, 1, 2), (15, 4, 5), (27, 1, 2), ((13, 7), 2, 3), (11, 4, 5), (11, 5, 5), (19, 6, 6), (7, 5, 5)])
 def test_other_windows_and_view_counts_bit_exact(box, n_best, n_src):
     """the general-window kernels (pm_core_lut.h: runtime radius — the reference's default box is 19 = 100 taps —, weights from

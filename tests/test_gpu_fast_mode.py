@@ -41,9 +41,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEPTH_REL = 1e-3          # |depth_fast - depth_ref| / depth_ref
 ANGLE_DEG = 0.1           # angle between the normals
 COST_P50, COST_P99, COST_MAX = 1e-5, 1e-4, 1e-3     # |cost_fast(plane) - cost_oracle(plane)|; measured 4e-6 / 5e-5 / 3e-4
-# floors for the pixel-wise agreement of whole runs (measured values: gpurun_out/fast_mode_metrics.json)
-CFG1_DEPTH_1E3, CFG1_DEPTH_1E2 = 0.88, 0.995      # 640x480: f = 358 px, a 1e-3 depth change is 0.004 px of disparity
-CFG2_DEPTH_1E3, CFG2_DEPTH_1E2 = 0.99, 0.999      # 6048x4032: f = 3387 px
+# Pixel-wise agreement of whole runs has no floor fitted to a measurement (rounds 2-3 had 0.88 / 0.99 / 0.98, set from what was
+# observed).  The bar is relative and the same for every configuration: at each level fast may disagree with the reference
+# arithmetic at most HALF as often as the reference arithmetic disagrees with ITSELF under another RNG seed — which is what the
+# reference does to itself on every launch (curand_init(clock64()), gipuma.cu:700,1077).  Measured ratios: 0.04-0.24 at 1e-3,
+# 0.00-0.07 at 1e-2 (gpurun_out/fast_mode_metrics.json).
+CONTROL_SHARE = 0.5
 
 
 def _record(key, value):
@@ -97,6 +100,8 @@ def _normal_error_deg(normal, gt_normal_world):
 def _better_than_control(agree, control):
     for k in ("identical_depth", "depth_within_1e-4", "depth_within_1e-3", "depth_within_1e-2", "angle_within_0.1deg", "angle_within_1deg"):
         assert agree[k] >= control[k] - 0.002, (k, agree[k], control[k])
+    for k in ("depth_within_1e-3", "depth_within_1e-2"):      # disagreement <= half the reseeded control's
+        assert 1.0 - agree[k] <= CONTROL_SHARE * (1.0 - control[k]) + 1e-5, (k, agree[k], control[k])
 
 
 def test_cfg1_fast_run_vs_oracle():
@@ -127,7 +132,6 @@ def test_cfg1_fast_run_vs_oracle():
     agree["control_oracle_vs_oracle_reseeded"] = control
     _record("cfg1_fast_vs_oracle_640x480_4views_8iters", agree)
     _better_than_control(agree, control)
-    assert agree["depth_within_1e-3"] >= CFG1_DEPTH_1E3 and agree["depth_within_1e-2"] >= CFG1_DEPTH_1E2, agree
     assert agree["valid_mismatch"] < 1e-3, agree
     # the same solution, statistically
     assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_oracle"]) < 1e-3, agree
@@ -164,7 +168,6 @@ def test_cfg2_fast_run_vs_strict_full_size():
     agree["control_strict_vs_strict_reseeded"] = control
     _record("cfg2_fast_vs_strict_6048x4032_10views_8iters", agree)
     _better_than_control(agree, control)
-    assert agree["depth_within_1e-3"] >= CFG2_DEPTH_1E3 and agree["depth_within_1e-2"] >= CFG2_DEPTH_1E2, agree
     assert agree["valid_mismatch"] < 1e-3, agree
     assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_strict"]) < 5e-4, agree
     assert abs(agree["mean_cost_fast"] - agree["mean_cost_strict"]) < 2e-5, agree
@@ -200,7 +203,6 @@ def test_other_windows_fast_run_vs_strict(box, n_best):
     _record(f"box{box}_nbest{n_best}_fast_vs_strict_{w}x{h}_{n}views_6iters", agree)
     _better_than_control(agree, control)
     # f = 1129 px here: a 1e-3 depth change is 0.011 px of disparity (between cfg1's 0.004 and cfg2's 0.034)
-    assert agree["depth_within_1e-3"] >= 0.98 and agree["depth_within_1e-2"] >= 0.9995, agree      # measured 0.990 / 0.9989 / 0.9993 and 0.9999+
     assert agree["valid_mismatch"] < 1e-3, agree
     assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_strict"]) < 2e-3, agree
     assert abs(agree["mean_cost_fast"] - agree["mean_cost_strict"]) < 1e-4, agree
@@ -254,7 +256,7 @@ def test_diverged_pixels_are_valid_patchmatch_steps(mid_scene, colour):
     assert (worse > COST_P99).mean() < 0.01 if div.any() else True, rec      # ... and beyond its p99 in under 1 % of the diverged pixels
     assert np.percentile(gap, 50) <= COST_P99 if div.any() else True, rec    # the two outcomes are near-ties by the oracle's own score
     assert (cost[swept] <= start_c[swept]).all()             # greedy in the GPU's own arithmetic: strictly never up
-    assert same[swept].mean() >= 0.80, rec
+    assert same[swept].mean() > 0.5, rec                     # recorded, not fitted (85-86 % measured): the checks above carry the statement
 
 
 def test_cost_of_a_given_plane_percentiles(small_scene, mid_scene):

@@ -40,7 +40,7 @@ int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, in
 }
 
 // The same quads as four halfs per entry, (t00, d1 = t10 - t00, d2 = t01 - t00, d3 = t11 - t10 - t01 + t00): what the fast
-// arithmetic's blend t00 + ax d1 + ay d2 + (ax ay) d3 consumes (oracle S7 (6)).  All four are integers of magnitude <= 510, exact in
+// arithmetic's blend (t00 + ax d1) + ay (d2 + ax d3) consumes (oracle S7 (6)).  All four are integers of magnitude <= 510, exact in
 // fp16, so three v_fma_mix_f32 read them straight out of the gathered 8 bytes — no byte converts, no subtractions (pm_tap_r5.h MIX).
 __global__ __launch_bounds__(EW_BLOCK) void build_dquad_kernel(const uint32_t* __restrict__ quad, uint2* __restrict__ dquad, int64_t n) {
     for (int64_t k = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * EW_BLOCK) {

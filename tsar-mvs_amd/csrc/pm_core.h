@@ -28,7 +28,7 @@
 typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
 typedef const float __attribute__((address_space(1)))* global_f32_ptr;
 
-// DIFF (fast arithmetic only, oracle S7 (6)): the blend as t00 + ax d1 + ay d2 + (ax ay) d3 over the texel differences
+// DIFF (fast arithmetic only, oracle S7 (6)): the blend as (t00 + ax d1) + ay (d2 + ax d3) over the texel differences
 template <bool QUAD, bool DIFF = false>
 DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u, float v, bool q8 = false) {
     // tex2D(tex, u + .5, v + .5), linear filter, clamp addressing (main.cpp:1215-1219).
@@ -56,7 +56,7 @@ DEVFN float sample_bilinear(const DevView& vw, int w, int h, int qpitch, float u
     }
     if (DIFF) {
         const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
-        return fma_(ax * ay, d3, fma_(ay, d2, fma_(ax, d1, t00)));
+        return fma_(ay, fma_(ax, d3, d2), fma_(ax, d1, t00));
     }
     const float top = fma_(ax, t10 - t00, t00);
     const float bot = fma_(ax, t11 - t01, t01);
@@ -144,7 +144,7 @@ DEVFN float view_cost_generic(const DevScene* __restrict__ sc, const DevView& vw
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
     float H[9];
-    if (STRICT) plane_homography(sc->ref, vw, n4, H);
+    if (STRICT) plane_homography(sc->ref, vw, n4, H, sc->k_sparse != 0);
     else plane_homography_fast(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     int tap = 0;

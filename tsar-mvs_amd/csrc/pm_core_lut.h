@@ -86,7 +86,7 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     const int rt = ROW ? hr : vr, rl = ROW ? vr : hr;       // radius along / across the lines
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
     float H[9];
-    if (STRICT) plane_homography(sc->ref, vw, n4, H);
+    if (STRICT) plane_homography(sc->ref, vw, n4, H, sc->k_sparse != 0);
     else plane_homography_fast(sc->ref, vw, n4, H);
     // clamp-free loop when the four corner taps of every active lane land inside the source image with Z > 0 and a pixel of
     // margin (pm_core.h, variant bit 4): wave-uniform, identical results.  In fast mode the padding slots of a row's last chunk
@@ -223,11 +223,10 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
             if constexpr (MIX) {
                 asm("s_waitcnt vmcnt(%3)" : "+v"(q2[jj]), "+v"(sum_src_src) : "v"(q2[CH - 1]), "n"(CH - 1 - jj));
                 const uint32_t lo = (uint32_t)q2[jj], hi = (uint32_t)(q2[jj] >> 32);
-                const float axay = ax[jj] * ay[jj];
-                float tt;
-                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tt) : "v"(ax[jj]), "v"(lo));          // ax * d1 + t00
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(tt) : "v"(ay[jj]), "v"(hi), "v"(tt));                // ay * d2 + .
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(s) : "v"(axay), "v"(hi), "v"(tt));    // (ax ay) * d3 + .
+                float ta, tb;
+                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(ta) : "v"(ax[jj]), "v"(lo));          // ax * d1 + t00: the top row's interpolation
+                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tb) : "v"(ax[jj]), "v"(hi));          // ax * d3 + d2: bottom row minus top row, rounded once
+                s = fma_(ay[jj], tb, ta);
             } else {
             if constexpr (BUF)      // the asm-issued gathers return in order: tap jj has CH - 1 - jj behind it (waits chained, pm_core.h)
                 asm("s_waitcnt vmcnt(%3)" : "+v"(q[jj]), "+v"(sum_src_src) : "v"(q[CH - 1]), "n"(CH - 1 - jj));
@@ -241,7 +240,7 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
                 s = fma_(ay[jj], bot - top, top);
             } else {                                            // fast arithmetic (oracle S7 (6)), see pm_tap_r5.h
                 const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
-                s = fma_(ax[jj] * ay[jj], d3, fma_(ay[jj], d2, fma_(ax[jj], d1, t00)));
+                s = fma_(ay[jj], fma_(ax[jj], d3, d2), fma_(ax[jj], d1, t00));
             }
             }
             const float wt = wv[jj];

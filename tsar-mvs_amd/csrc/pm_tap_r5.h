@@ -18,8 +18,8 @@
 //           sweep of a view, so the launcher uses it from the third sweep on).  No compiler builtin reaches idxen: the loads are
 //           issued by asm and their vmcnt waits are written out.
 //   MIX     with BUF, fast mode: the gather reads 8 bytes from the view's half-float difference texture (t00, t10 - t00, t01 - t00,
-//           t11 - t10 - t01 + t00; plane_kernels.hip build_dquad_kernel) and the fast arithmetic's blend t00 + ax d1 + ay d2 + (ax ay) d3
-//           is three v_fma_mix_f32 on the halfs in place: no byte converts, no subtractions (-7.5 issue units of a tap's 34).  Same
+//           t11 - t10 - t01 + t00; plane_kernels.hip build_dquad_kernel) and the fast arithmetic's blend (t00 + ax d1) + ay (d2 + ax d3)
+//           is two v_fma_mix_f32 on the halfs in place and one v_fma_f32: no byte converts, no subtractions (-9 issue units of a tap's 34).  Same
 //           values bit for bit as the byte-texture form of that blend, which the global-load launches (init, the first two sweeps) keep.
 //           (Strict mode can form the reference's blend from the same halfs bit-exactly — t10 - t00 is stored, t01 and t11 - t01 are
 //           one exact v_fma_mix_f32 each, -4.5 issue units per tap — and was measured SLOWER, 48.1 -> 51.6 ms per launch: its
@@ -43,7 +43,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     const int w = sc->w, h = sc->h, qp = sc->quad_pitch;
     const int qorg = (qp + 1) << 2;          // byte offset of quad entry (0 + 1, 0 + 1)
     float H[9];
-    if (STRICT) plane_homography(sc->ref, vw, n4, H);
+    if (STRICT) plane_homography(sc->ref, vw, n4, H, sc->k_sparse != 0);
     else plane_homography_fast(sc->ref, vw, n4, H);
     float sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f;
     // Clamp-free loop: if the four corner taps of every active lane's window land inside the source image with Z > 0 (the window
@@ -218,14 +218,13 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             }
             float s;
             if (MIX) {
-                // t00 + ax d1 + ay d2 + (ax ay) d3 with the halfs read in place: three fused multiply-adds with one fp32 rounding
-                // each, the same values as the fp32 chain below (the halfs are exact integers)
+                // (t00 + ax d1) + ay (d2 + ax d3) with the halfs read in place: two mixed-precision FMAs on the gathered dwords and one
+                // plain FMA, one fp32 rounding each — the same values as the fp32 chain below (the halfs are exact integers)
                 const uint32_t lo = (uint32_t)q2[jj], hi = (uint32_t)(q2[jj] >> 32);
-                const float axay = ax[jj] * ay[jj];
-                float tt;
-                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tt) : "v"(ax[jj]), "v"(lo));          // ax * d1 + t00
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(tt) : "v"(ay[jj]), "v"(hi), "v"(tt));                // ay * d2 + .
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(s) : "v"(axay), "v"(hi), "v"(tt));    // (ax ay) * d3 + .
+                float ta, tb;
+                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(ta) : "v"(ax[jj]), "v"(lo));          // ax * d1 + t00: the top row's interpolation
+                asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(tb) : "v"(ax[jj]), "v"(hi));          // ax * d3 + d2: bottom row minus top row, rounded once
+                s = fma_(ay[jj], tb, ta);
             } else {
             asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(t00) : "v"(q[jj]));
             asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(t10) : "v"(q[jj]));
@@ -235,9 +234,9 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
                 const float top = fma_(ax[jj], t10 - t00, t00);
                 const float bot = fma_(ax[jj], t11 - t01, t01);
                 s = fma_(ay[jj], bot - top, top);
-            } else {                                            // fast arithmetic (oracle S7 (6)): t00 + ax d1 + ay d2 + (ax ay) d3, exact integer differences
+            } else {                                            // fast arithmetic (oracle S7 (6)): (t00 + ax d1) + ay (d2 + ax d3), exact integer differences
                 const float d1 = t10 - t00, d2 = t01 - t00, d3 = (t11 - t01) - d1;
-                s = fma_(ax[jj] * ay[jj], d3, fma_(ay[jj], d2, fma_(ax[jj], d1, t00)));
+                s = fma_(ay[jj], fma_(ax[jj], d3, d2), fma_(ax[jj], d1, t00));
             }
             }
             // one wait per line, at its first tap: every LDS load of the line (six texels when they are D16 loads, three weight

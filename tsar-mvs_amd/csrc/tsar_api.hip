@@ -139,7 +139,8 @@ static void derive_cameras(tsar_ctx* ctx, const tsar_camera* cams) {
         DevView& dv = sc.view[v];
         for (int i = 0; i < 9; i++) { dv.K[i] = (float)Kv[i]; dv.R[i] = (float)Rrel[i]; }
         for (int r = 0; r < 3; r++) dv.t[r] = (float)trel[r];
-        dv.pad_ = dv.pad2_ = 0.f;
+        dv.t_abs_lo = std::min(std::min(fabsf(dv.t[0]), fabsf(dv.t[1])), fabsf(dv.t[2]));
+        dv.t_abs_hi = std::max(std::max(fabsf(dv.t[0]), fabsf(dv.t[1])), fabsf(dv.t[2]));
         {                                                        // fast-mode split of the plane homography: A = K R K0^-1, b = K t
             double K0inv[9], KR[9], A[9];
             inv3(K0, K0inv);
@@ -172,6 +173,10 @@ static void derive_cameras(tsar_ctx* ctx, const tsar_camera* cams) {
             rf.depthMax = ctx->params.depth_max;
         }
     }
+    // zero / one pattern of the intrinsics (cam files without skew, the only kind MVSNet-format scenes carry)
+    auto sparse3 = [](const float* K) { return K[1] == 0.f && K[3] == 0.f && K[6] == 0.f && K[7] == 0.f && K[8] == 1.f; };
+    sc.k_sparse = sparse3(sc.ref.Kinv) ? 1 : 0;
+    for (int v = 0; v < ctx->n_views; v++) sc.k_sparse &= sparse3(sc.view[v].K) ? 1 : 0;
     // main.cpp:1393-1398
     sc.min_disp = sc.ref.f * sc.ref.baseline / ctx->params.depth_max;
     sc.max_disp = sc.ref.f * sc.ref.baseline / ctx->params.depth_min;

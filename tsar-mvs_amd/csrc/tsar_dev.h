@@ -21,10 +21,10 @@ struct DevView {
     float K[9];
     float R[9];
     float t[3];
-    float pad_;
+    float t_abs_lo;          // min |t[r]|, max |t[r]|: bounds of the nine products t[r] n[c] of the strict homography's operand guard
     float A[9];              // K R K_ref^-1  (fast-mode homography H = A - b m^T, m = K_ref^-T n / d)
     float b[3];              // K t
-    float pad2_;
+    float t_abs_hi;
     const float* img;        // [h][w] float gray
     const uint32_t* quad;    // [(h+2)][(w+2)] packed 2x2 texel quads (8-bit images only), see plane_kernels.hip build_quad_kernel
     const uint2* dquad;      // [(h+2)][(w+2)] the same quads as four halfs (t00, t10 - t00, t01 - t00, t11 - t10 - t01 + t00): fast mode's converged sweeps (pm_tap_r5.h MIX), else null
@@ -55,6 +55,8 @@ struct DevScene {
     float min_disp, max_disp;
     uint32_t flags;
     uint32_t seed_lo, seed_hi;
+    int k_sparse;              // every view's K is (fx 0 cx; 0 fy cy; 0 0 1) and K_ref^-1 has the same zero / one pattern (no skew):
+                               // the strict homography then skips the products with those zeros (plane_homography, tsar_device_math.h)
     DevRef ref;
     int sel[TSAR_MAX_VIEWS];   // view indices in pair.txt order
     DevView view[TSAR_MAX_VIEWS];

@@ -139,7 +139,12 @@ DEVFN void view_vector(const DevRef& rf, int x, int y, float* v) {
     v[2] = X[2] * inv;
 }
 // getHomography_cu gipuma.cu:207-224: H = K_src (R - t n^T / d) K_ref^-1
-DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n4, float* H) {
+// k_sparse (wave-uniform, DevScene): K_src = (fx 0 cx; 0 fy cy; 0 0 1) and K_ref^-1 of the same pattern.  Inside the operand guard
+// every element of M and T is finite, so a product with one of those zeros is (+-)0 and adding it returns the other addend: the two
+// 3x3 products of matmul_cu (config.h:205-230) then need 15 + 12 operations instead of 27 + 27, with the oracle's values — up to
+// the SIGN of an element that is exactly zero (R[e] equal to its quotient to the last bit), which no later step can tell apart: a
+// zero H element only ever meets finite factors, and tap fractions / indices come out of floor and x - floor(x).
+DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n4, float* H, bool k_sparse = false) {
     const float n[3] = {n4.x, n4.y, n4.z};
     float M[9], T[9];
     // outer product, then every element divided by d (matdivide, config.h:139-148): nine correctly rounded quotients over one
@@ -151,20 +156,42 @@ DEVFN void plane_homography(const DevRef& rf, const DevView& vw, const float4& n
 #pragma unroll
         for (int c = 0; c < 3; c++) P[r * 3 + c] = vw.t[r] * n[c];
     const float d = n4.w;
-    float lo = __builtin_fabsf(d), hi = lo;
-#pragma unroll
-    for (int e = 0; e < 9; e++) { lo = __builtin_fminf(lo, __builtin_fabsf(P[e])); hi = __builtin_fmaxf(hi, __builtin_fabsf(P[e])); }
+    // Guard over the nine |P[e]| and |d|.  Rounding is monotonic, so min |fl(t[r] n[c])| = fl(min|t| min|n|) and likewise the
+    // maximum: two products bound all nine exactly (the view's min / max |t[r]| come with the view, the plane's are two
+    // three-operand instructions that do not depend on the view) — the same decision as nine v_min + nine v_max, for six instructions
+    const float nlo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n[0]), __builtin_fabsf(n[1])), __builtin_fabsf(n[2]));
+    const float nhi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n[0]), __builtin_fabsf(n[1])), __builtin_fabsf(n[2]));
+    const float lo = __builtin_fminf(vw.t_abs_lo * nlo, __builtin_fabsf(d)), hi = __builtin_fmaxf(vw.t_abs_hi * nhi, __builtin_fabsf(d));
     if (__builtin_expect(__any(!(lo >= TSAR_DIV_GUARD_LO && hi <= TSAR_DIV_GUARD_HI)), 0)) {
 #pragma unroll
         for (int e = 0; e < 9; e++) M[e] = vw.R[e] - P[e] / d;
-    } else {
-        const float r0 = __builtin_amdgcn_rcpf(d);
-        const float rc = fma_(fma_(-d, r0, 1.0f), r0, r0);
+        mat3mul(M, rf.Kinv, T);
+        mat3mul(vw.K, T, H);
+        return;
+    }
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float rc = fma_(fma_(-d, r0, 1.0f), r0, r0);
 #pragma unroll
-        for (int e = 0; e < 9; e++) {
-            const float q = P[e] * rc;
-            M[e] = vw.R[e] - fma_(fma_(-q, d, P[e]), rc, q);
+    for (int e = 0; e < 9; e++) {
+        const float q = P[e] * rc;
+        M[e] = vw.R[e] - fma_(fma_(-q, d, P[e]), rc, q);
+    }
+    if (k_sparse) {
+        const float* Ki = rf.Kinv;
+        const float* K = vw.K;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            T[r * 3 + 0] = M[r * 3] * Ki[0];                                                  // + M1 * 0 + M2 * 0
+            T[r * 3 + 1] = M[r * 3 + 1] * Ki[4];                                              // M0 * 0 + . + M2 * 0
+            T[r * 3 + 2] = fma_(M[r * 3 + 2], Ki[8], fma_(M[r * 3 + 1], Ki[5], M[r * 3] * Ki[2]));
         }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            H[c] = fma_(K[2], T[6 + c], K[0] * T[c]);                                         // K01 = 0
+            H[3 + c] = fma_(K[5], T[6 + c], K[4] * T[3 + c]);                                 // K10 = 0: fma(fy, T1c, 0) = fy T1c
+            H[6 + c] = T[6 + c];                                                              // (0 0 1)
+        }
+        return;
     }
     mat3mul(M, rf.Kinv, T);
     mat3mul(vw.K, T, H);

@@ -10,7 +10,7 @@ DEVFN float reverse_cost(const DevScene* __restrict__ sc, const DevView& vw, int
     const int hr = sc->hrad, vr = sc->vrad;
     const DevView& rv = sc->view[0];
     float H[9], V[9];
-    plane_homography(sc->ref, vw, n4, H);
+    plane_homography(sc->ref, vw, n4, H, sc->k_sparse != 0);
     // inverse homography by the adjugate, gipuma.cu:316-337
     const float det = H[0] * H[4] * H[8] + H[1] * H[5] * H[6] + H[2] * H[3] * H[7] - H[2] * H[4] * H[6] - H[1] * H[3] * H[8] - H[0] * H[5] * H[7];
     V[0] = (H[4] * H[8] - H[5] * H[7]) / det;
