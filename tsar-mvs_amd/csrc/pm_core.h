@@ -202,8 +202,12 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
     const int num = sc->n_sel;
     int valid = 0, bv = -1;
     float cmin = __builtin_inff();
+    int vi_next = sc->sel[0];
     for (int i = 0; i < num; i++) {
-        const int vi = sc->sel[i];
+        // the NEXT view's index is loaded now (scalar load, wave-uniform), a whole view of tap loops ahead of its use: otherwise
+        // every view starts with two dependent scalar-memory round trips (index, then camera block) in front of its first instruction
+        const int vi = vi_next;
+        vi_next = sc->sel[i + 1 < num ? i + 1 : i];
         float c;
         // V names the tap loop: bit 10 = the general-window loop (chunk length in bits 11-13), a production variant of the box-11
         // loop (pm_tap_r5.h), 0 = the generic one-tap loop; anything else exists in the experiments build only

@@ -83,7 +83,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     // quad base + border offset, opaque to the optimiser so that it stays in two SGPRs across the view (the compiler otherwise
     // re-loads it with s_load in every line and waits for it, and for the line's LDS loads, right before issuing the gathers)
     uint32_t qb_lo = 0, qb_hi = 0;
-    {
+    if (!BUF) {                              // (the buffer-load forms address through the descriptor below: no second pointer load per view)
         const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)qorg;
         qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qa);
         qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qa >> 32));
@@ -92,12 +92,12 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
     u32x4s rsrc = {0u, 0u, 0u, 0u};
     if (BUF) {
-        const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)qorg;
         if (MIX) {                           // 8-byte entries of the difference texture, same pitch and border
             const uint64_t da = (uint64_t)(uintptr_t)vw.dquad + 2 * (uint64_t)(uint32_t)qorg;
             rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)da);
             rsrc.y = __builtin_amdgcn_readfirstlane(((uint32_t)(da >> 32) & 0xffffu) | (8u << 16));  // base[47:32] | stride 8
         } else {
+        const uint64_t qa = (uint64_t)(uintptr_t)vw.quad + (uint32_t)qorg;
         rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)qa);
         rsrc.y = __builtin_amdgcn_readfirstlane(((uint32_t)(qa >> 32) & 0xffffu) | (4u << 16));      // base[47:32] | stride 4
         }
@@ -107,8 +107,12 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // one line of the window: `i` is the column offset (the row offset when ROW) and the six taps run along the other axis
-    auto line6 = [&](int i, auto clamp_tag) {
+    // unr_tag: the caller's loop over the six lines is fully unrolled (`i` is a constant after inlining): the line's LDS loads then
+    // take their line offset as an immediate from loop-invariant base addresses instead of two address additions per line
+    auto line6 = [&](int i, auto clamp_tag, auto unr_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
+        constexpr bool UNR = decltype(unr_tag)::value;
+        static_assert(!UNR || (ROW && D16), "the unrolled form is written for the row-wise walk with D16 window loads");
         const float xi = (float)((ROW ? y : x) + i);
         const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
         const int line = (i + 5) >> 1;                // 0..5: which column (or row) this is
@@ -118,20 +122,21 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             // the line's six weights, [tap][thread] layout, tap = 6 * column + row: taps are BLK floats apart = BLK / 64 units of
             // ds_read2st64's 256-byte stride; along a row consecutive taps are 6 taps apart
             constexpr int U = BLK / 64, S = ROW ? 6 : 1;
-            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + (ROW ? line : 6 * line) * BLK);
+            const uint32_t wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(wts + (UNR ? 0 : (ROW ? line : 6 * line) * BLK));
 #pragma unroll
             for (int k = 0; k < 3; k++)
-                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(2 * U * S * k), "n"(2 * U * S * k + U * S), "v"(bz));
+                asm("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(wcol[k]) : "v"(wa), "n"(2 * U * S * k + (UNR ? U * line : 0)), "n"(2 * U * S * k + U * S + (UNR ? U * line : 0)), "v"(bz));
         }
         if (D16) {
             // The loads are invisible to the compiler's waitcnt bookkeeping, which stays correct (LDS returns in order, its own
             // waits only get more conservative); the wait for these six is the asm before their first use below.  Neither asm is
             // volatile (a volatile one fences the gathers and serialises the taps); the unused bz operand keeps the loads inside
             // the line loop instead of being hoisted out of the view and hypothesis loops into 36 live registers.
-            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(ROW ? tile + own + i * tw - 5 : tile + own + i - 5 * tw);
+            // (UNR: base = the window's first row; the window is PM_RW + 10 texels wide in every kernel that runs this loop)
+            const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned short*)(UNR ? tile + own - 5 * tw - 5 : ROW ? tile + own + i * tw - 5 : tile + own + i - 5 * tw);
 #pragma unroll
             for (int jj = 0; jj < 6; jj++)
-                asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"(ROW ? jj * 4 : jj * 2 * (PM_RW + 10) * 2), "v"(bz));
+                asm("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(rcol[jj]) : "v"(a0), "n"((ROW ? jj * 4 : jj * 2 * (PM_RW + 10) * 2) + (UNR ? line * 2 * (PM_RW + 10) * 2 : 0)), "v"(bz));
         }
         float ax[6], ay[6];
         uint32_t q[6];
@@ -259,10 +264,15 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     };
     if (need_clamp) {
 #pragma unroll 1
-        for (int i = -5; i <= 5; i += 2) line6(i, std::true_type());
+        for (int i = -5; i <= 5; i += 2) line6(i, std::true_type(), std::false_type());
+    } else if constexpr (MIX && DIAG == 0) {
+        // the converged launches' hot path: the six lines unrolled (-6 VALU and the loop's scalar bookkeeping per line; +0.65 %
+        // Mpix/s, profiles/r04/ab_unrolled_lines)
+#pragma unroll
+        for (int i = -5; i <= 5; i += 2) line6(i, std::false_type(), std::true_type());
     } else {
 #pragma unroll 1
-        for (int i = -5; i <= 5; i += 2) line6(i, std::false_type());
+        for (int i = -5; i <= 5; i += 2) line6(i, std::false_type(), std::false_type());
     }
     sum_src *= pr.inv_wsum;
     sum_src_src *= pr.inv_wsum;
