@@ -56,3 +56,21 @@ def test_no_instruction_touches_a_gather_in_flight(tmp_path, unit):
     bad, n = chk.check(str(out))
     assert n >= 36, "the translation unit no longer contains the asm-issued gathers this test guards"
     assert not bad, "\n".join(bad[:10])
+    # Register budget of the production kernels, from the assembler's own metadata: every sweep kernel must fit the 128 VGPRs that four
+    # waves per SIMD leave, WITHOUT scratch.  (Round 4 shipped, for an hour, a launch bound that read 1024 / BLK = 8 waves for the
+    # 128-thread shape: 64 VGPRs + 224 B of scratch per lane — still bit-exact, so no parity test saw it, and cfg1 ran 22 % slower.)
+    import re
+    txt = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+        name, body = m.group(1), m.group(2)
+        mv = re.search(r"pm_sweep_kernelILi(\d+)ELi\d+ELb[01]ELb1ELi(\d+)ELi(?:128|256)E", name)
+        if not mv or int(mv.group(2)) == 0:          # (variant 0 = the generic one-tap loop of float imagery: not the bench path)
+            continue
+        seen += 1
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane"
+        if int(mv.group(1)) <= 4:                    # (the 32-entry best-N selection of long lists is allowed its extra registers)
+            assert vgpr <= 128, f"{name}: {vgpr} VGPRs (four waves per SIMD need <= 128)"
+    assert seen >= 4

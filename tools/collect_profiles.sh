@@ -18,7 +18,13 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ
 timeout -k 10 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum \
     --kernel-include-regex pm_sweep --output-format csv -d $O/pmc_tcp -- python3 bench.py $P > $O/bench_pmc_tcp.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex pm_sweep --output-format csv -d $O/pmc_fetch -- python3 bench.py $P > $O/bench_pmc_fetch.log 2>&1 &&
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex pm_sweep --output-format csv -d $O/pmc_write -- python3 bench.py $P > $O/bench_pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex pm_sweep --output-format csv -d $O/pmc_write -- python3 bench.py $P > $O/bench_pmc_write.log 2>&1 &&
+# strict mode's sweeps (round 4: what bounds the oracle-exact kernel): the same two counter sets with the strict record left in
+# (rows whose kernel name carries <..., true, true, 122 / 131194, ...> are the strict launches)
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES \
+    --kernel-include-regex pm_sweep --output-format csv -d $O/pmc_strict_sq -- python3 bench.py --steps 1 --warmup 0 --iters 3 --no-cpu-baseline --no-host-boundary > $O/bench_pmc_strict_sq.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum \
+    --kernel-include-regex pm_sweep --output-format csv -d $O/pmc_strict_tcp -- python3 bench.py --steps 1 --warmup 0 --iters 3 --no-cpu-baseline --no-host-boundary > $O/bench_pmc_strict_tcp.log 2>&1
 rc=$?
 # the per-dispatch trace is tens of MB (torch renders the synthetic scene); keep the matcher's own launches only
 for f in $O/stats/*/*kernel_trace.csv; do

@@ -102,7 +102,7 @@ DEVFN bool same_bits(const float4& a, const float4& b) {
 }
 
 template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
-__global__ __launch_bounds__(BLK, ((V & 512) || (V & 2097152) ? 1024 / BLK : 1)) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
+__global__ __launch_bounds__(BLK, ((V & 512) ? 1024 / BLK : 1)) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
                                                             const float* __restrict__ c_same, const float4* __restrict__ n_same,
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
