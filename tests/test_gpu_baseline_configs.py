@@ -132,7 +132,7 @@ def test_cfg2_full_size_properties():
 @pytest.mark.parametrize("w,h", [(192, 128), (101, 67)])
 def test_both_workgroup_shapes_bit_exact(monkeypatch, block, w, h):
     """the sweep runs as 256-thread (32 x 16 pixel) workgroups, or 128-thread (32 x 8) ones on small images; small test scenes
-    would only ever see the latter, so both shapes are forced here (TSAR_BLOCK is read at every launch)"""
+    would only ever see the latter, so both shapes are forced here (TSAR_BLOCK is read by tsar_create: set before the matcher exists)"""
     monkeypatch.setenv("TSAR_BLOCK", block)
     sc = synth.make_scene(w, h, 4, seed=31)
     orc = _oracle(sc, seed=23)

@@ -90,7 +90,7 @@ def _sweep_cost(m, planes):
 
 @pytest.fixture
 def block_shape(request):
-    """TSAR_BLOCK (read per launch): the sweep's 128-thread workgroups (what an image this small gets) or the 256-thread shape of
+    """TSAR_BLOCK (read once per context, by tsar_create: the fixture sets it before the matchers are made): the sweep's 128-thread workgroups (what an image this small gets) or the 256-thread shape of
     full-size images"""
     old = os.environ.get("TSAR_BLOCK")
     os.environ["TSAR_BLOCK"] = str(request.param)

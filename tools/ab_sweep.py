@@ -47,7 +47,7 @@ os.environ.pop("TSAR_VARIANT", None)
 for r in range(args.rounds + 1):
     for v in variants:
         m, sweep, init, env = ms[v]
-        os.environ.update(env)                      # knobs read per launch (TSAR_BLOCK) as well as per context
+        os.environ.update(env)                      # (harmless: every knob is read once, when the context is created)
         m.reset_kernel_timing()
         m.pm_init()
         m.pm_iterate(args.iters)
