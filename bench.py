@@ -310,6 +310,12 @@ def main():
         if pending[k] is not None:
             for wk in pending[k]:
                 wk.wait()
+            if backend == "nccl":
+                # RCCL work.wait() only makes torch's CURRENT STREAM wait for the collective; the matcher's kernels run on the
+                # context's own stream and the host would run ahead.  Drain the current stream so that "the gather has finished
+                # reading this buffer set" is a fact on the host before anything is launched that may overwrite it (the gather was
+                # issued a whole view earlier, so this never waits in practice).
+                torch.cuda.current_stream().synchronize()
             pending[k] = None
 
     def step():
