@@ -39,8 +39,10 @@ static int launch_sweep_nh(tsar_ctx* ctx, int colour, const PlaneBuf& a, const P
     const bool strict = ctx->hscene.flags & TSAR_FLAG_STRICT_DIV, quad = ctx->hscene.use_quad;
     // structured buffer loads for the gathers (pm_tap_r5.h BUF) from the third sweep of a run on: measured per launch
     // (tools/launch_series.sh) they take 0.6 ms off a converged launch (37.6 -> 37.0) and add 4 ms to the first sweep after the
-    // random initialisation (55.1 -> 59.1), where neighbouring lanes' footprints are unrelated, and 0.3 ms to the second (41.0 -> 41.3)
-    const bool buf = ctx->buffer_gather && ctx->sweeps_done >= 2;
+    // random initialisation (55.1 -> 59.1), where neighbouring lanes' footprints are unrelated, and 0.3 ms to the second (41.0 -> 41.3).
+    // Fast mode on the difference texture (round 4: its cheaper blend outweighs the doubled footprint already on the SECOND
+    // sweep, -1.7 ms per view; on the first it costs 28 ms): from sweep ctx->buffer_from = 1 on.
+    const bool buf = ctx->buffer_gather && ctx->sweeps_done >= (strict ? (ctx->buffer_from > 2 ? ctx->buffer_from : 2) : ctx->buffer_from);
     // The production configuration (8-bit quad textures, box 11, <= 4 best views) runs the hand-scheduled tap loop of pm_tap_r5.h in
     // both arithmetic modes: variant 250 in fast mode (row-wise walk), 122 in strict mode (the oracle's column order; also the
     // column-order fast loop, TSAR_VARIANT=122), 114 where the D16 probe fails; + 131072 with buffer loads.

@@ -15,7 +15,7 @@
 //           tsar_create probes this once (pm_sweep.hip) and the library falls back to D16 = false if it does not hold.
 //   BUF     the gathers as structured buffer loads (buffer_load_dword ... idxen) through a stride-4 resource descriptor: the texture
 //           addresser scales the element index, the per-tap shift goes away (-0.65 % on a converged launch, +4 ms on the first
-//           sweep of a view, so the launcher uses it from the third sweep on).  No compiler builtin reaches idxen: the loads are
+//           sweep of a view, so the launcher uses it from the second sweep on in fast mode, the third in strict mode).  No compiler builtin reaches idxen: the loads are
 //           issued by asm and their vmcnt waits are written out.
 //   MIX     with BUF, fast mode: the gather reads 8 bytes from the view's half-float difference texture (t00, t10 - t00, t01 - t00,
 //           t11 - t10 - t01 + t00; plane_kernels.hip build_dquad_kernel) and the fast arithmetic's blend (t00 + ax d1) + ay (d2 + ax d3)

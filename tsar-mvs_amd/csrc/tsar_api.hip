@@ -248,6 +248,7 @@ static void read_knobs(tsar_ctx* ctx) {
     ctx->buffer_gather = on("TSAR_BUFFER_GATHER", true);
     ctx->mix_gather = on("TSAR_MIX_GATHER", true);
     ctx->strip_w = num("TSAR_STRIP", -1);
+    ctx->buffer_from = num("TSAR_BUFFER_FROM", 1);
     ctx->force_block = num("TSAR_BLOCK", 0);
     ctx->lut_mode = num("TSAR_LUT", 1);
     ctx->ransac_wgs = num("TSAR_RANSAC_WGS", 8);

@@ -128,6 +128,7 @@ struct tsar_ctx {
                                  // -1 = automatic: one vertical band of the image per XCD (see strip_width)
     // The remaining environment knobs (DESIGN.md §4 lists them all).  Everything is read ONCE, by tsar_create (tsar_api.hip
     // read_knobs): a context never looks at the environment again, and no knob is latched in a function-local static.
+    int buffer_from = 1;         // TSAR_BUFFER_FROM=n: fast mode's sweeps use buffer-load gathers on the difference texture from sweep n of a run on (default 1: only the first sweep, whose planes are random, keeps global loads on the byte texture; measured 0 / 1 / 2 -> 37.19 / 35.33 / 35.44 ms mean sweep, profiles/r04); strict mode from max(n, 2)
     int force_block = 0;         // TSAR_BLOCK=128|256: force the sweep's workgroup shape (0: by image size, SWEEP_SMALL_IMAGE_TILES)
     int lut_mode = 1;            // TSAR_LUT=0: one-tap loop for windows other than box 11; 2: box 11 through the general-window loop too
     int ransac_wgs = 8;          // TSAR_RANSAC_WGS: workgroups per region in RANSAC stage 2 (1 = the single-workgroup kernel)
