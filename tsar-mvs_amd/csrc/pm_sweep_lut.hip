@@ -17,14 +17,14 @@ int lut_chunk_taps(int T) {
 template <int NB, bool STRICT>
 static int launch_sweep_lut_ns(tsar_ctx* ctx, int ch, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr) {
     // fast mode, from the third sweep of a run on: gathers as structured buffer loads (variant bit 17, see pm_sweep.hip)
-    if (!STRICT && ctx->buffer_gather && ctx->sweeps_done >= 2 && ctx->hscene.n_sel > 0 && ctx->hscene.view[ctx->hscene.sel[0]].dquad != nullptr) {
+    if (!STRICT && ctx->buffer_gather && ctx->sweeps_done >= ctx->buffer_from && ctx->hscene.n_sel > 0 && ctx->hscene.view[ctx->hscene.sel[0]].dquad != nullptr) {
         switch (ch) {      // + bit 21: the half-float difference texture (pm_tap_r5.h MIX) when tsar_set_views built it
             case 4: return launch_sweep_t<NB, 0, false, true, LUT_V(4) | 131072 | 2097152>(ctx, colour, a, b, c, sid, dp, dr);
             case 5: return launch_sweep_t<NB, 0, false, true, LUT_V(5) | 131072 | 2097152>(ctx, colour, a, b, c, sid, dp, dr);
             default: return launch_sweep_t<NB, 0, false, true, LUT_V(6) | 131072 | 2097152>(ctx, colour, a, b, c, sid, dp, dr);
         }
     }
-    if (!STRICT && ctx->buffer_gather && ctx->sweeps_done >= 2) {
+    if (!STRICT && ctx->buffer_gather && ctx->sweeps_done >= ctx->buffer_from) {
         switch (ch) {
             case 4: return launch_sweep_t<NB, 0, false, true, LUT_V(4) | 131072>(ctx, colour, a, b, c, sid, dp, dr);
             case 5: return launch_sweep_t<NB, 0, false, true, LUT_V(5) | 131072>(ctx, colour, a, b, c, sid, dp, dr);
