@@ -178,7 +178,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
             int lin;
             asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(lin) : "v"(iv), "s"(qp), "v"(iu));
             if (MIX && DIAG == 1) {
-                q2[jj] = ((uint64_t)(uint32_t)lin << 32) | (uint32_t)lin;
+                q2[jj] = ((uint64_t)(uint32_t)~lin << 32) | (uint32_t)lin;      // (two different dwords: identical ones would let the compiler merge the blend's two mixed FMAs)
             } else if (MIX && DIAG == 2) {
                 uint32_t la;                                    // inside the workgroup's first 32 KiB of LDS, lanes 16 bytes apart like a staged patch
                 asm("v_bfe_u32 %0, %1, 0, 12" : "=v"(la) : "v"(lin));
@@ -265,7 +265,7 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
     if (need_clamp) {
 #pragma unroll 1
         for (int i = -5; i <= 5; i += 2) line6(i, std::true_type(), std::false_type());
-    } else if constexpr (MIX && DIAG == 0) {
+    } else if constexpr (MIX) {
         // the converged launches' hot path: the six lines unrolled (-6 VALU and the loop's scalar bookkeeping per line; +0.65 %
         // Mpix/s, profiles/r04/ab_unrolled_lines)
 #pragma unroll
