@@ -48,6 +48,6 @@ static void run(const char* name, kfn k, double* d_out, int wps) {
 }
 int main() {
     double* d_out; hipMalloc(&d_out, 256 * 8 * 256 * sizeof(double));
-    for (int wps : {2, 4}) { run("fma_f32", k_fma_f32, d_out, wps); run("min_f64", k_min_f64, d_out, wps); run("max_f64", k_max_f64, d_out, wps); run("fma_f64", k_fma_f64, d_out, wps); run("add_f64", k_add_f64, d_out, wps); }
+    for (int wps : {1, 2, 4}) { run("fma_f32", k_fma_f32, d_out, wps); run("min_f64", k_min_f64, d_out, wps); run("max_f64", k_max_f64, d_out, wps); run("fma_f64", k_fma_f64, d_out, wps); run("add_f64", k_add_f64, d_out, wps); }
     return 0;
 }

@@ -3,179 +3,139 @@
 // (fill of unreliable pixels in textured regions, :1294-1497).
 //
 // The reference bubble-sorts four (value, weight) lists of up to 121 taps per pixel in 5 kB of
-// per-thread local memory, O(n^2) data-moving swaps.  Here the same sorted order is obtained without
-// moving data: each tap's rank is counted (stable: ties keep tap order) with the list held in VGPRs, and the
-// lists are walked in rank order.  The reference's sort also touches slot `num` (a zero entry joins and the largest entry
-// drops out); that is reproduced by ranking num+1 entries and walking the first num.
+// per-thread local memory, O(n^2) data-moving swaps.  Here the same STABLE sorted order (ties keep tap order) comes out of a
+// sorting network on 64-bit (value, slot) keys held in registers (sort_order below), and the lists are walked in that order.
+// The reference's sort also touches slot `num` (a zero entry joins and the largest entry drops out); that is
+// reproduced by sorting num + 1 entries and walking the first num.
 // Neighbours are read from launch-start copies of scale / depth / planes (the reference reads what
 // other threads of the same launch are writing).
 #include "tsar_device_math.h"
 
 #define WMF_BLOCK 64
 #define WMF_SLOTS 122   // 11 x 11 tap slots in enumeration order + the zero slot the reference's sort drags in (slot 121)
-#define WMF_REGS 128    // the list being ranked, in registers: four 32-float vectors
 
 // Tap slots are kept in ENUMERATION order (i outer, j inner: slot = 11 ii + jj), invalid ones flagged, instead of being
-// compacted: the compacted index of the reference (`num++`) is monotone in the slot number, so stable order and ranks among
-// the valid taps are the same — and a slot number is wave-uniform, which is what lets the list being ranked live in VGPRs.
-// Only the weights persist per thread (scratch, 488 B: they are read by per-lane rank order in the walks).  The values being
-// ranked are re-gathered from the launch-start planes list by list — reads that neighbouring pixels share through L1 / L2 —
-// instead of being parked in scratch (five more arrays, ~2.4 KB per thread and ~580 MB of private memory in flight chip-wide,
-// which is HBM traffic); the pixel a slot refers to is recomputed from the slot number.
+// compacted: the compacted index of the reference (`num++`) is monotone in the slot number, so the stable order among the valid taps
+// is the same — and a slot number is a compile-time constant of the unrolled key construction.  The weights live in LDS
+// ([slot][thread]: a walk's per-lane slot lands every lane on its own bank); the values being sorted are re-gathered from the
+// launch-start planes list by list — reads that neighbouring pixels share through L1 / L2; the pixel a slot refers to is recomputed
+// from the slot number.
 struct WmfTaps {
-    float w[WMF_SLOTS];
     uint64_t valid_lo, valid_hi;   // bit t of (hi:lo): slot t holds a tap (slot 121, the zero slot, always does)
     int num;                       // number of valid taps, excluding the zero slot
     int x, y, radius, gap;         // geometry of the tap grid
 };
-DEVFN bool slot_valid(const WmfTaps& t, int k) { return ((k < 64 ? t.valid_lo >> k : t.valid_hi >> (k - 64)) & 1u) != 0; }
-// pixel index of tap slot k (k < 121): slot = 11 ii + jj, offsets (-radius + ii gap, -radius + jj gap)
-DEVFN int slot_pixel(const WmfTaps& t, int k, int w) {
-    const int ii = k / 11, jj = k - 11 * ii;
-    return (t.y - t.radius + jj * t.gap) * w + (t.x - t.radius + ii * t.gap);
-}
-// the same for a slot number that comes out of the ranking (per-lane): never outside the image, whatever the list held
+// pixel of tap slot k (k < 121; slot = 11 ii + jj, offsets (-radius + ii gap, -radius + jj gap)), clamped into the image: a slot
+// number that comes out of a walk is per-lane
 DEVFN int slot_pixel_safe(const WmfTaps& t, int k, int w, int h) {
     const int ii = k / 11, jj = k - 11 * ii;
     const int px = min(max(t.x - t.radius + ii * t.gap, 0), w - 1), py = min(max(t.y - t.radius + jj * t.gap, 0), h - 1);
     return py * w + px;
 }
-enum WmfList { WMF_DEPTH = 0, WMF_NX = 1, WMF_NY = 2, WMF_NZ = 3 };
-template <int LIST>
-DEVFN float slot_value(const float* __restrict__ depth_in, const float4* __restrict__ n_in, int q) {
-    if (LIST == WMF_DEPTH) return depth_in[q];
-    const float* nn = (const float*)(n_in + q);
-    return nn[LIST - 1];
-}
-
 // Per-workgroup staging of the sorted order: pos[r] = slot with stable rank r (bytes, [rank][thread]).
 struct WmfLds {
-    unsigned char pos[WMF_SLOTS * WMF_BLOCK];
+    float w[WMF_SLOTS * WMF_BLOCK];             // bilateral weight of every tap slot, [slot][thread]
+    unsigned char pos[WMF_SLOTS * WMF_BLOCK];   // the list's sorted order, [rank][thread]
 };
 
-typedef float f32x32 __attribute__((ext_vector_type(32)));
-
-// Counting without condition masks.  `r += (vj <= vk)` compiles to v_cmp (writes an SGPR pair) + v_addc (reads it): on gfx950
-// a VALU-written SGPR needs two wait states before a VALU read (hipcc pads every pair with s_nop 1), and instructions that
-// take a lane mask from SGPRs issue far slower than plain VGPR arithmetic (measured: 127 ms per launch with masks, even with
-// the eight compares hoisted ahead of the eight adds).  The order of two floats is the sign of their difference — exact in
-// IEEE arithmetic, zero only for equal operands; list entries are loaded as v + 0.0f so that -0 cannot appear, invalid slots
-// are +inf — so each comparison is a v_sub_f32 whose sign bit is shifted into a 32-bit register (v_alignbit_b32), and one
-// v_bcnt_u32_b32 per register and 32 comparisons adds the ones up: VGPR-only, full rate.
-//   before-loop (entries that sort first on ties): vj <= vk  <=>  sign(vk - vj) == 0   -> counts zeros
-//   after-loop:                                     vj <  vk  <=>  sign(vj - vk) == 1   -> counts ones
-struct SignCount8 {
-    uint32_t s[8];
-    DEVFN void clear() {
-#pragma unroll
-        for (int c = 0; c < 8; c++) s[c] = 0u;
-    }
-    // push sign(a[c] - b) (FLIP = false) or sign(b - a[c]) (FLIP = true)
-    template <bool FLIP>
-    DEVFN void push(const float (&a)[8], float b) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const float d = FLIP ? b - a[c] : a[c] - b;
-            s[c] = __builtin_amdgcn_alignbit(s[c], __float_as_uint(d), 31);      // (s << 1) | sign(d)
-        }
-    }
-    DEVFN void add_ones(int (&r)[8]) const {
-#pragma unroll
-        for (int c = 0; c < 8; c++) r[c] += __builtin_popcount(s[c]);
-    }
-    DEVFN void add_zeros(int (&r)[8], int pushed) const {
-#pragma unroll
-        for (int c = 0; c < 8; c++) r[c] += pushed - __builtin_popcount(s[c]);
-    }
-};
-
-// pos[r] = slot of the entry with stable rank r among the valid slots (the zero slot included).
-// The reference bubble-sorts each list in 5 kB of per-thread local memory; the previous version of this kernel counted ranks
-// from an LDS copy of the list (39 KB per 64 threads -> one wave per SIMD, LDS-latency bound, 233 ms per launch at 24 Mpixel).
-// Here the list sits in 128 VGPRs of its thread — the register file is the largest on-chip memory of a CU, 512 KB — and entry j,
-// j wave-uniform, is read with a relative-index move (s_set_gpr_idx_on + v_mov): no LDS or scratch access in the O(n^2) part.
-// Eight entries are ranked per pass: one indexed move feeds eight compare / add-carry pairs.  Invalid slots hold +inf, which
-// is never "before" a valid entry.
-template <int LIST>
-DEVFN void rank_order(const float* __restrict__ depth_in, const float4* __restrict__ n_in, int w, const WmfTaps& t, WmfLds& l) {
-    const int tid = threadIdx.x;
-    f32x32 R0, R1, R2, R3;
-    const float inf = __builtin_inff();
-    auto load = [&](int k) -> float {                      // k is a compile-time constant after unrolling
-        if (k == WMF_SLOTS - 1) return 0.0f;               // the zero slot
-        if (k >= WMF_SLOTS) return inf;
-        return slot_valid(t, k) ? slot_value<LIST>(depth_in, n_in, slot_pixel(t, k, w)) + 0.0f : inf;     // + 0.0f: -0 -> +0 (see SignCount8)
-    };
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-        R0[k] = load(k);
-        R1[k] = load(32 + k);
-        R2[k] = load(64 + k);
-        R3[k] = load(96 + k);
-    }
-    auto entry = [&](int j) -> float {                    // j wave-uniform
-        const int q = __builtin_amdgcn_readfirstlane(j);
-        if (q < 32) return R0[q];
-        if (q < 64) return R1[q - 32];
-        if (q < 96) return R2[q - 64];
-        return R3[q - 96];
-    };
-    for (int k0 = 0; k0 < WMF_SLOTS; k0 += 8) {
-        float vk[8];
-        int r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 8; c++) vk[c] = entry(min(k0 + c, WMF_SLOTS - 1));
-        // entries before all eight: ties sort first.  One loop per 32-register vector, so that the choice of vector is not a
-        // branch per entry (k0 is a multiple of 8: the ranges end on vector boundaries or inside one vector)
-        // (at most 32 comparisons per sub-loop: one sign register per entry and sub-loop)
-        SignCount8 sc;
-#define WMF_BEFORE(VEC, LO, HI)                                                                  \
-        if (k0 > (LO)) {                                                                         \
-            const int hi_ = min(k0, (HI));                                                       \
-            sc.clear();                                                                          \
-            for (int j = (LO); j < hi_; j++) sc.push<false>(vk, VEC[__builtin_amdgcn_readfirstlane(j - (LO))]);   \
-            sc.add_zeros(r, hi_ - (LO));                                                         \
-        }
-        WMF_BEFORE(R0, 0, 32)
-        WMF_BEFORE(R1, 32, 64)
-        WMF_BEFORE(R2, 64, 96)
-        WMF_BEFORE(R3, 96, WMF_SLOTS)
-#undef WMF_BEFORE
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {                             // the eight themselves
-            if (k0 + jj >= WMF_SLOTS) break;
-            const float vj = vk[jj];
-#pragma unroll
-            for (int c = 0; c < 8; c++) r[c] += (jj < c) ? (vj <= vk[c]) : ((jj > c) ? (vj < vk[c]) : 0);
-        }
-        // entries after all eight
-#define WMF_AFTER(VEC, LO, HI)                                                                   \
-        if (k0 + 8 < (HI)) {                                                                     \
-            sc.clear();                                                                          \
-            for (int j = max(k0 + 8, (LO)); j < (HI); j++) sc.push<true>(vk, VEC[__builtin_amdgcn_readfirstlane(j - (LO))]);   \
-            sc.add_ones(r);                                                                      \
-        }
-        WMF_AFTER(R0, 0, 32)
-        WMF_AFTER(R1, 32, 64)
-        WMF_AFTER(R2, 64, 96)
-        WMF_AFTER(R3, 96, WMF_SLOTS)
-#undef WMF_AFTER
-#pragma unroll
-        for (int c = 0; c < 8; c++)
-            if (k0 + c < WMF_SLOTS && slot_valid(t, k0 + c)) l.pos[r[c] * WMF_BLOCK + tid] = (unsigned char)(k0 + c);
-    }
+// ---- the stable order from a SORTING NETWORK on (value, slot) keys ---------------------------------------------------------------------
+// Rounds 2-3 counted every tap's rank: O(n^2), 122^2 comparisons of 2 instructions per list with the list in 128 VGPRs (233 ms per
+// launch in round 1 from an LDS copy, 104.6 with the registers and mask-free sign counting).  A sorting network is O(n log^2 n), but the order wanted
+// is the STABLE one — ties keep tap order, and ties are the common case (planes spread by verbatim copies) — so the key has to carry
+// the slot, and a two-register key would need its payload moved through lane masks (v_cndmask issues at 7.7x a v_fma here).  The way
+// out: ONE 64-bit key whose ordering by v_min_f64 / v_max_f64 IS the lexicographic order of (value, slot).  The tap's fp32 value
+// converts to fp64 exactly and leaves the low 29 mantissa bits zero; the slot number (7 bits) goes into the lowest bits — for a
+// negative value 127 - slot, since a larger mantissa is then the smaller number.  Two different floats differ by at least 2^29
+// double-ulps, so the slot bits only ever break ties, in tap order.  +0 with slot bits is a subnormal double (fp64 subnormals are not
+// flushed in this mode): zeros order by slot and stay between the negatives and the positives.  Invalid slots get huge keys
+// (2^1023 + slot) and sort last; a NaN value becomes 2^1022 + slot (v_min_f64 returns the other operand), so the keys are always a
+// permutation.  A compare-exchange is two instructions, the network (wmf_sort_network.h: Batcher's odd-even merge sort, 1401
+// comparators) 2 802 per list against ~30 000 for the counting; the 122 keys live in 244 VGPRs (the rest spills to AGPRs), so the
+// kernel runs ONE wave per SIMD — with a ninth of the instructions to issue, and with everything a lone wave would wait for kept
+// short: the values of a list are loaded in batches of 32 before the first is converted, weights and sorted slots live in LDS.
+// Measured at 24 MP: 100 -> 65 ms per detection launch with the weights still in scratch, see profiles/r04.
+DEVFN double wmf_key(float v, int k, uint32_t valid_mask) {       // valid_mask: all ones / zero
+    const double d = (double)(v + 0.0f);                          // + 0.0f: -0 -> +0
+    uint32_t lo = (uint32_t)__double_as_longlong(d), hi = (uint32_t)((unsigned long long)__double_as_longlong(d) >> 32);
+    const uint32_t m = (uint32_t)((int32_t)hi >> 31);             // all ones for a negative value
+    lo |= (uint32_t)k ^ (m & 127u);
+    double key = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    const double nan_key = __longlong_as_double((long long)((0x7FD00000ull << 32) | (unsigned)k));
+    asm("v_min_f64 %0, %1, %2" : "=v"(key) : "v"(key), "v"(nan_key));                    // NaN -> its own large key
+    lo = (uint32_t)__double_as_longlong(key); hi = (uint32_t)((unsigned long long)__double_as_longlong(key) >> 32);
+    hi = (hi & valid_mask) | (0x7FE00000u & ~valid_mask);         // invalid slot: 2^1023 + k
+    lo = (lo & valid_mask) | ((uint32_t)k & ~valid_mask);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// clamped: with NaN values in a list the counted ranks are no permutation and a rank may stay unwritten (stale LDS byte)
+DEVFN int wmf_key_slot(double key) {
+    const uint32_t lo = (uint32_t)__double_as_longlong(key), hi = (uint32_t)((unsigned long long)__double_as_longlong(key) >> 32);
+    const uint32_t m = (uint32_t)((int32_t)hi >> 31);
+    return (int)((lo ^ (m & 127u)) & 127u);
+}
+// pos[r] = slot with stable rank r among the valid slots (the zero slot included), for list `list` (0 depth, 1..3 normal components):
+// wave-uniform runtime argument, so that the network exists once in the binary
+__device__ __noinline__ void sort_order(int list, const float* __restrict__ depth_in, const float4* __restrict__ n_in, int w, int h, const WmfTaps& t, WmfLds& l) {
+    // (global address space spelled out: a generic pointer out of a select compiles to flat loads)
+    typedef const float __attribute__((address_space(1)))* gptr;
+    const gptr base = list == 0 ? (gptr)depth_in : (gptr)((const float*)n_in + (list - 1));
+    const int stride = list == 0 ? 1 : 4;
+    const uint32_t vw[4] = {(uint32_t)t.valid_lo, (uint32_t)(t.valid_lo >> 32), (uint32_t)t.valid_hi, (uint32_t)(t.valid_hi >> 32)};
+    double key[WMF_SLOTS];
+    // values in batches of 32, software-pipelined: the loads of batch b + 1 are issued before batch b is converted (one wave per SIMD
+    // has nobody else to hide a load's latency behind, and while the keys are still being made there are registers to spare)
+    auto load_batch = [&](int k0, float (&v)[32]) {
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+            const int k = k0 + u;
+            if (k >= WMF_SLOTS - 1) break;
+            const int ii = k / 11, jj = k - 11 * ii;
+            // (clamped like slot_pixel_safe: a slot outside the image is invalid, its value is loaded from the border and discarded)
+            const int px = min(max(t.x - t.radius + ii * t.gap, 0), w - 1), py = min(max(t.y - t.radius + jj * t.gap, 0), h - 1);
+            v[u] = base[(py * w + px) * stride];
+        }
+    };
+    auto make_batch = [&](int k0, const float (&v)[32]) {
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+            const int k = k0 + u;
+            if (k >= WMF_SLOTS - 1) break;
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_sbfe((int)vw[k >> 5], k & 31, 1);      // v_bfe_i32 of one bit: 0 or all ones
+            key[k] = wmf_key(v[u], k, mask);
+        }
+    };
+    {
+        float va[32], vb[32];
+        load_batch(0, va);
+        load_batch(32, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        make_batch(0, va);
+        load_batch(64, va);
+        __builtin_amdgcn_sched_barrier(0);
+        make_batch(32, vb);
+        load_batch(96, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        make_batch(64, va);
+        make_batch(96, vb);
+    }
+    key[WMF_SLOTS - 1] = __longlong_as_double((long long)(WMF_SLOTS - 1));       // the zero slot: value +0, slot 121, always valid
+#define CE(I, J) { double lo_, hi_; asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo_), "=&v"(hi_) : "v"(key[I]), "v"(key[J])); key[I] = lo_; key[J] = hi_; }
+#include "wmf_sort_network.h"
+#undef CE
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < WMF_SLOTS; r++) l.pos[r * WMF_BLOCK + tid] = (unsigned char)wmf_key_slot(key[r]);
+}
+
+// (clamped: a slot number is at most 121 whatever the byte holds)
 DEVFN int pos_at(const WmfLds& l, int i) { return min((int)l.pos[i * WMF_BLOCK + threadIdx.x], WMF_SLOTS - 1); }
 // Cumulative weight in rank order (gipuma.cu:1618-1650): acc += w[pos[i]] for i = 0 .. num-1, sequentially — the fp32 sums must
-// be formed in exactly this order.  Each step is an LDS read (the slot) feeding a scratch read (its weight) at a per-lane
-// address; taken one at a time that is ~1.5 us of latency per step (the weights of all resident waves do not fit L2).  So the
-// walk goes in batches of 16: the 16 slots, then the 16 weights, are in flight together, and only the adds are sequential.
+// be formed in exactly this order.  Each step is an LDS read (the slot) feeding a second LDS read (its weight) at a per-lane
+// address; the walk goes in batches of 16: the 16 slots, then the 16 weights, are in flight together, and only the adds are sequential.
 // Lanes past their own num add the zero slot's weight (acc + 0.0f == acc).  Returns the total; *kmed = the slot at which the
 // sum first reaches `half`, or the last walked slot if it never does (FIND only).
 #define WMF_WALK 16
 template <bool FIND>
-DEVFN float walk_ranked(const float* w, const WmfLds& l, int num, float half, int* kmed) {
+DEVFN float walk_ranked(const WmfLds& l, int num, float half, int* kmed) {
     float acc = 0.f;
     bool found = false;
     int kfound = WMF_SLOTS - 1, klast = WMF_SLOTS - 1;
@@ -185,7 +145,7 @@ DEVFN float walk_ranked(const float* w, const WmfLds& l, int num, float half, in
 #pragma unroll
         for (int u = 0; u < WMF_WALK; u++) k[u] = (i0 + u < num) ? pos_at(l, i0 + u) : WMF_SLOTS - 1;
 #pragma unroll
-        for (int u = 0; u < WMF_WALK; u++) wv[u] = w[k[u]];
+        for (int u = 0; u < WMF_WALK; u++) wv[u] = l.w[k[u] * WMF_BLOCK + threadIdx.x];
 #pragma unroll
         for (int u = 0; u < WMF_WALK; u++) {
             acc += wv[u];
@@ -199,41 +159,52 @@ DEVFN float walk_ranked(const float* w, const WmfLds& l, int num, float half, in
     if (FIND) *kmed = found ? kfound : klast;
     return acc;
 }
-DEVFN int weighted_median_slot(const float* w, const WmfLds& l, int num, float half) {
+DEVFN int weighted_median_slot(const WmfLds& l, int num, float half) {
     int k;
-    walk_ranked<true>(w, l, num, half, &k);
+    walk_ranked<true>(l, num, half, &k);
     return k;
 }
-template <int LIST>
-DEVFN float value_of_slot(const float* __restrict__ depth_in, const float4* __restrict__ n_in, int w, int h, const WmfTaps& t, int k) {
-    return k == WMF_SLOTS - 1 ? 0.0f : slot_value<LIST>(depth_in, n_in, slot_pixel_safe(t, k, w, h));
-}
-
-DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict__ scale_in, int x, int y, int radius, int gap, float sdiv, WmfTaps& t) {
+DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict__ scale_in, int x, int y, int radius, int gap, float sdiv, WmfTaps& t, WmfLds& l) {
     const float* __restrict__ img = sc->view[0].img;
     const int w = sc->w, h = sc->h;
     const float cen = img[(size_t)y * w + x];
-    int num = 0, slot = 0;
+    int num = 0;
     uint64_t lo = 0, hi = 0;
-    for (int i = -radius; i <= radius; i += gap)
-        for (int j = -radius; j <= radius; j += gap, slot++) {
-            const int px = x + i, py = y + j;
-            bool ok = px >= 0 && px < w && py >= 0 && py < h;
-            const size_t q = ok ? (size_t)py * w + px : 0;
-            ok = ok && scale_in[q] == 1.0f;
+    // The grid is 11 x 11 in every launch (radius = 5 gap).  One column of 11 taps at a time: the 22 loads (reliability flag and
+    // image value, from clamped positions) are issued together and the taps computed afterwards — the kernel runs one wave per SIMD,
+    // so a load that waits for the one before it is time nobody else fills.
+    typedef const float __attribute__((address_space(1)))* gptr;
+    const gptr gscale = (gptr)scale_in, gimg = (gptr)img;
+#pragma unroll 1
+    for (int ii = 0; ii < 11; ii++) {
+        const int i = -radius + ii * gap, px = x + i;
+        const bool okx = px >= 0 && px < w;
+        const int pxc = min(max(px, 0), w - 1);
+        float sv[11], iv[11];
+#pragma unroll
+        for (int jj = 0; jj < 11; jj++) {
+            const int pyc = min(max(y - radius + jj * gap, 0), h - 1);
+            sv[jj] = gscale[pyc * w + pxc];
+            iv[jj] = gimg[pyc * w + pxc];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 11; jj++) {
+            const int j = -radius + jj * gap, py = y + j, slot = 11 * ii + jj;
+            const bool ok = okx && py >= 0 && py < h && sv[jj] == 1.0f;
             float wt = 0.f;
             if (ok) {
-                const float cd = fabsf(img[q] - cen);
+                const float cd = fabsf(iv[jj] - cen);
                 const float sd = sqrtf((float)(i * i + j * j)) / sdiv;
                 wt = tsar_expf(-sd / 4.0f) * tsar_expf(-cd / 9.0f);   // sigma_spatial 2, sigma_color 3 (gipuma.cu:1537-1550)
                 num++;
                 if (slot < 64) lo |= 1ull << slot; else hi |= 1ull << (slot - 64);
             }
-            t.w[slot] = wt;
+            l.w[slot * WMF_BLOCK + threadIdx.x] = wt;
         }
+    }
     // the zero slot the reference's sort drags in: value 0, weight 0, after every tap
     const int zs = WMF_SLOTS - 1;
-    t.w[zs] = 0.f;
+    l.w[zs * WMF_BLOCK + threadIdx.x] = 0.f;
     hi |= 1ull << (zs - 64);
     t.valid_lo = lo; t.valid_hi = hi;
     t.num = num;
@@ -246,8 +217,8 @@ DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict
                         float4& out) {
     const DevRef& rf = sc->ref;
     const int num = t.num, w = sc->w;
-    rank_order<WMF_DEPTH>(depth_in, n_in, w, t, l);
-    const float wsum = walk_ranked<false>(t.w, l, num, 0.f, nullptr);
+    sort_order(0, depth_in, n_in, w, sc->h, t, l);
+    const float wsum = walk_ranked<false>(l, num, 0.f, nullptr);
     const float half = wsum / 2.f;
     int weimid = -1;
     {
@@ -261,7 +232,7 @@ DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict
 #pragma unroll
             for (int u = 0; u < WMF_WALK; u++) k[u] = (i0 + u < num) ? pos_at(l, i0 + u) : WMF_SLOTS - 1;
 #pragma unroll
-            for (int u = 0; u < WMF_WALK; u++) wv[u] = t.w[k[u]];
+            for (int u = 0; u < WMF_WALK; u++) wv[u] = l.w[k[u] * WMF_BLOCK + threadIdx.x];
 #pragma unroll
             for (int u = 0; u < WMF_WALK; u++) {
                 acc += wv[u];
@@ -271,12 +242,12 @@ DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict
         if (found) weimid = kf == WMF_SLOTS - 1 ? 0 : slot_pixel_safe(t, kf, w, sc->h);   // n[] of the zero slot is 0
     }
     float nm[3];
-    rank_order<WMF_NX>(depth_in, n_in, w, t, l);
-    nm[0] = value_of_slot<WMF_NX>(depth_in, n_in, w, sc->h, t, weighted_median_slot(t.w, l, num, half));
-    rank_order<WMF_NY>(depth_in, n_in, w, t, l);
-    nm[1] = value_of_slot<WMF_NY>(depth_in, n_in, w, sc->h, t, weighted_median_slot(t.w, l, num, half));
-    rank_order<WMF_NZ>(depth_in, n_in, w, t, l);
-    nm[2] = value_of_slot<WMF_NZ>(depth_in, n_in, w, sc->h, t, weighted_median_slot(t.w, l, num, half));
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        sort_order(1 + c, depth_in, n_in, w, sc->h, t, l);
+        const int k = weighted_median_slot(l, num, half);
+        nm[c] = k == WMF_SLOTS - 1 ? 0.0f : ((const float*)(n_in + slot_pixel_safe(t, k, w, sc->h)))[c];     // n[] of the zero slot is 0
+    }
     if (weimid < 0) return false;
     const float depth_mid = rf.f * rf.baseline / depth_in[weimid];
     const double nrm = (double)sqrtf(dot3(nm, nm));   // `double xyzsqr = sqrtf(..)`, gipuma.cu:1663-1666
@@ -288,7 +259,7 @@ DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict
     return true;
 }
 
-__global__ __launch_bounds__(WMF_BLOCK, 3) void wmf_detect_kernel(const DevScene* __restrict__ sc, const float* __restrict__ scale_in,
+__global__ __launch_bounds__(WMF_BLOCK, 1) void wmf_detect_kernel(const DevScene* __restrict__ sc, const float* __restrict__ scale_in,
                                                                const float* __restrict__ depth, const float4* __restrict__ n4,
                                                                float* __restrict__ scale_out, int iter) {
     const int w = sc->w, h = sc->h;
@@ -301,7 +272,7 @@ __global__ __launch_bounds__(WMF_BLOCK, 3) void wmf_detect_kernel(const DevScene
     WmfTaps t;
     float4 nm;
     float s = 0.0f;
-    if (collect_taps(sc, scale_in, x, y, radius, gap, (float)repo, t) > 0 && median_plane(sc, depth, n4, t, lds, nm)) {
+    if (collect_taps(sc, scale_in, x, y, radius, gap, (float)repo, t, lds) > 0 && median_plane(sc, depth, n4, t, lds, nm)) {
         const DevRef& rf = sc->ref;
         const float fb = rf.f * rf.baseline;
         const float disp_now = fb / plane_depth(rf, nm, x, y);
@@ -311,7 +282,7 @@ __global__ __launch_bounds__(WMF_BLOCK, 3) void wmf_detect_kernel(const DevScene
     scale_out[p] = s;
 }
 
-__global__ __launch_bounds__(WMF_BLOCK, 3) void wmf_fill_kernel(const DevScene* __restrict__ sc, const int32_t* __restrict__ canny,
+__global__ __launch_bounds__(WMF_BLOCK, 1) void wmf_fill_kernel(const DevScene* __restrict__ sc, const int32_t* __restrict__ canny,
                                                              const float* __restrict__ region_text, const float* __restrict__ scale_in,
                                                              const float* __restrict__ depth_in, const float4* __restrict__ n_in,
                                                              float* __restrict__ scale_out, float* __restrict__ depth_out,
@@ -326,7 +297,7 @@ __global__ __launch_bounds__(WMF_BLOCK, 3) void wmf_fill_kernel(const DevScene* 
     __shared__ WmfLds lds;
     WmfTaps t;
     float4 nm;
-    const int num = collect_taps(sc, scale_in, x, y, radius, gap, (float)po, t);
+    const int num = collect_taps(sc, scale_in, x, y, radius, gap, (float)po, t, lds);
     if (num < ths || num == 0) return;
     if (!median_plane(sc, depth_in, n_in, t, lds, nm)) return;
     const DevRef& rf = sc->ref;
