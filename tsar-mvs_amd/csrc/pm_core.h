@@ -186,9 +186,6 @@ DEVFN float view_cost_generic(const DevScene* __restrict__ sc, const DevView& vw
 }
 
 #include "pm_tap_r5.h"     // view_cost_r5: the production loop for box 11 on 8-bit imagery (variants 114 / 122 / 250, + 131072 = buffer loads)
-#ifdef TSAR_EXPERIMENTS
-#include "pm_core_experiments.h"   // view_cost_variants: measured-and-rejected / diagnostic tap loops (TSAR_VARIANT)
-#endif
 #include "pm_core_lut.h"   // view_cost_lut: any window, weights from a shared table (variant bit 10; chunk length in bits 11-13)
 
 // pmCostMultiview_cu gipuma.cu:455-518: best-N combination over the selected views.  The NB
@@ -217,10 +214,9 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
 #ifdef TSAR_EXPERIMENTS
         else if constexpr (QUAD && HR == 5 && r5_diag_variant(V))
             c = view_cost_r5<false, true, true, true, true, BLK, (V & 4194304) ? 1 : 2>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
-        else if constexpr (V != 0) c = view_cost_variants<HR, STRICT, QUAD, V, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
 #endif
         else {
-            static_assert(V == 0, "tap-loop variant not in this build (make TSAR_EXPERIMENTS=1)");
+            static_assert(V == 0, "unknown tap-loop variant");
             c = view_cost_generic<HR, STRICT, QUAD, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         }
         if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;

@@ -1,5 +1,7 @@
-// pm_sweep_experiments.hip — dispatch of the measured-and-rejected / diagnostic tap-loop variants (pm_core_experiments.h, pm_tap_r5.h
-// DIAG).  Built only into libtsar_hip_exp.so (`make TSAR_EXPERIMENTS=1`); selected with TSAR_VARIANT / TSAR_VARIANT_NOW.
+// pm_sweep_experiments.hip — dispatch of the diagnostic tap-loop variants (pm_tap_r5.h DIAG: the ceilings of profiles/r04) and of the
+// production variants forced into every launch.  Built only into libtsar_hip_exp.so (`make TSAR_EXPERIMENTS=1`); selected with
+// TSAR_VARIANT / TSAR_VARIANT_NOW.  (The measured-and-rejected tap loops of rounds 1-3 — lane maps, paired gathers, pipelined lines,
+// the LDS-patch sweep — were removed in round 4; their numbers are in profiles/r01-r03 and DESIGN.md section 4.)
 #include "pm_sweep_impl.h"
 
 int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& a, const PlaneBuf& b, const PlaneBuf& c, uint32_t sid, int dp, int dr, int* launched) {
@@ -17,35 +19,12 @@ int launch_pm_sweep_experiment(tsar_ctx* ctx, int colour, const PlaneBuf& a, con
         ctx->err = "TSAR_VARIANT: the difference-texture tap loop needs the views' dquad textures (fast mode, TSAR_MIX_GATHER on)";
         return TSAR_ERR_STATE;
     }
-    if (strict) {
-        switch (variant) {
-            EXP(true, 58);
-            EXP(true, 50);
-            default: return TSAR_OK;
-        }
-    }
+    if (strict) return TSAR_OK;
     switch (variant) {
-        EXP(false, 762);       // 250 + gathers of line t+1 issued before line t is blended
-        EXP(false, 655610);    // buffer loads + division-free corner test
-        EXP(false, 131290);    // buffer loads, no wave priority
-        EXP(false, 393466);    // 250 + buffer loads, issued back to back
-        EXP(false, 65786);     // 250 + 64 x 8 region: 2 x 32 lanes per wave
-        EXP(false, 16634);     // 250 + 8 x 8 lanes per wave
-        EXP(false, 33018);     // 250 + 16 x 4 lanes per wave
-        EXP(false, 506);       // WRONG RESULTS: the instruction mix of pairing two taps into one 16-byte gather
-        EXP(false, 254);       // WRONG RESULTS: 250 without gathers (texel bits synthesised from the address): the VALU floor
-        EXP(false, 131322);    // the production buffer-load loop in EVERY launch (the library uses it from the third sweep on)
+        EXP(false, 131322);    // the production buffer-load loop on the byte texture in EVERY launch (the library uses the difference texture from the second sweep on)
         EXP(false, 2228474);   // the production difference-texture loop (pm_tap_r5.h MIX) in EVERY launch (needs the context's dquad textures)
-        EXP(false, 6422778);   // WRONG RESULTS: the difference-texture loop without gathers: the VALU floor of the shipping body (pm_tap_r5.h DIAG 1)
-        EXP(false, 10617082);  // WRONG RESULTS: the difference-texture loop with every gather replaced by an 8-byte LDS read (DIAG 2)
-        EXP(false, 1048826);   // WRONG RESULTS: 250 with every gather replaced by an LDS read: the ceiling of an LDS-staged source patch
-        EXP(false, 2);
-        EXP(false, 6);
-        EXP(false, 10);
-        EXP(false, 18);
-        EXP(false, 26);
-        EXP(false, 50);
-        EXP(false, 58);
+        EXP(false, 6422778);   // WRONG RESULTS: the difference-texture loop without gathers: what the shipping body costs without its gather path (pm_tap_r5.h DIAG 1)
+        EXP(false, 10617082);  // WRONG RESULTS: the difference-texture loop with every gather replaced by an 8-byte LDS read (DIAG 2): the ceiling of LDS-staged source patches
         default: return TSAR_OK;
     }
 #undef EXP

@@ -102,7 +102,7 @@ DEVFN bool same_bits(const float4& a, const float4& b) {
 }
 
 template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
-__global__ __launch_bounds__(BLK, ((V & 512) ? 1024 / BLK : 1)) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
+__global__ __launch_bounds__(BLK) void pm_sweep_kernel(const DevScene* __restrict__ sc, int colour,
                                                             const float* __restrict__ c_same, const float4* __restrict__ n_same,
                                                             const float* __restrict__ c_other, const float4* __restrict__ n_other,
                                                             float* c_out, float4* n_out, float* __restrict__ ratio_out,
@@ -111,9 +111,8 @@ __global__ __launch_bounds__(BLK, ((V & 512) ? 1024 / BLK : 1)) void pm_sweep_ke
                                                             const float* __restrict__ final_text) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename TileOf<QUAD>::type TileT;
-    // region of a workgroup: 32 pixels wide (variant bit 16, experiments build: 64 wide and half as high — a wave then covers
-    // 2 rows x 32 pixels of the active colour)
-    constexpr int RW = (V & 65536) ? 2 * PM_RW : PM_RW;
+    // region of a workgroup: 32 pixels wide, 2 BLK / 32 high (one thread per pixel of the active colour)
+    constexpr int RW = PM_RW;
     constexpr int SWEEP_RH = 2 * BLK / RW;
     const int hr = HR > 0 ? HR : sc->hrad, vr = HR > 0 ? HR : sc->vrad;
     const int tw = RW + 2 * hr, th = SWEEP_RH + 2 * vr;
@@ -131,20 +130,11 @@ __global__ __launch_bounds__(BLK, ((V & 512) ? 1024 / BLK : 1)) void pm_sweep_ke
     stage_ref_tile<SWEEP_RH, TileT, BLK, RW>(sc, tile, tx0, ty0, hr, vr, LUTW ? LUT_TILE_PAD_ROWS : 0);
     __syncthreads();
 
-    // lane -> pixel: a wave covers 4 rows x 16 pixels of the active colour (a 32 x 4 pixel strip).  Variant bits 14 / 15
-    // (experiments build): the two other shapes the round-1 review asked to have measured — 8 rows x 8 pixels (16 x 8) and
-    // 16 rows x 4 pixels (8 x 16) per wave, four waves tiling the same 32 x 16 region
-    int ly = threadIdx.x >> 4, k = threadIdx.x & 15, xoff = 0;
-    if (V & 65536) { ly = threadIdx.x >> 5; k = threadIdx.x & 31; }
-    if ((V & 16384) && BLK == 256) {
-        const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-        ly = (wv >> 1) * 8 + (l >> 3); k = l & 7; xoff = (wv & 1) * 16;
-    } else if ((V & 32768) && BLK == 256) {
-        const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
-        ly = l >> 2; k = l & 3; xoff = wv * 8;
-    }
+    // lane -> pixel: a wave covers 4 rows x 16 pixels of the active colour (a 32 x 4 pixel strip).  The other shapes the round-1
+    // review asked to have measured lose: 8 x 8 pixels per wave +9.6 %, 16 rows x 4 +61 %, 2 rows x 32 +0.7 % (profiles/r02/ab_lane_maps.json)
+    const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
     const int y = ty0 + ly;
-    const int lx = xoff + 2 * k + ((colour + y) & 1);     // (x + y) & 1 == colour; gipuma.cu:1099-1103 / :1121-1125
+    const int lx = 2 * k + ((colour + y) & 1);            // (x + y) & 1 == colour; gipuma.cu:1099-1103 / :1121-1125
     const int x = tx0 + lx;
     const int w = sc->w, h = sc->h;
     if (x >= w || y >= h) return;
@@ -237,7 +227,7 @@ template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
                           uint32_t stream_id, int do_prop, int do_refine) {
     const DevScene& hs = ctx->hscene;
-    constexpr int RW = (V & 65536) ? 2 * PM_RW : PM_RW;
+    constexpr int RW = PM_RW;
     constexpr int SWEEP_RH = 2 * BLK / RW;
     const int tiles_x = (hs.w + RW - 1) / RW, tiles_y = (hs.h + SWEEP_RH - 1) / SWEEP_RH;
     const int n_tiles = tiles_x * tiles_y;
