@@ -94,6 +94,20 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     const int xr = ROW ? 2 * (sc->lut_pad_taps - 1) - hr : hr;
     bool inside = true;
     float zmin = __builtin_inff(), zmax = 0.0f;
+    if (!STRICT) {
+        // fast mode: the decision from the window's centre and a bound on its extent (pm_tap_r5.h): one reciprocal instead of four.
+        // |dx| <= max(hr, xr) (the padding slots reach further right than the window), |dy| <= vr
+        const float ex = (float)max(hr, xr), ey = (float)vr;
+        const float xc = (float)x, yc = (float)y;
+        const float Xc = fma_(H[1], yc, fma_(H[0], xc, H[2])), Yc = fma_(H[4], yc, fma_(H[3], xc, H[5])), Zc = fma_(H[7], yc, fma_(H[6], xc, H[8]));
+        const float a = fma_(ex, fabsf(H[0]), ey * fabsf(H[1])), b = fma_(ex, fabsf(H[3]), ey * fabsf(H[4])), c = fma_(ex, fabsf(H[6]), ey * fabsf(H[7]));
+        const float Zmin = Zc - c;
+        const float r = __builtin_amdgcn_rcpf(Zmin * Zc);
+        const float rc = Zmin * r;                                  // 1 / Zc
+        const float du = fma_(a, Zc, fabsf(Xc) * c) * r, dv = fma_(b, Zc, fabsf(Yc) * c) * r;
+        const float uc = Xc * rc, vc = Yc * rc;
+        inside = Zmin > 0.0f && fminf(uc - du, vc - dv) >= 1.5f && uc + du <= (float)(w - 1) - 1.5f && vc + dv <= (float)(h - 1) - 1.5f;
+    } else
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float xi = (float)(x + ((c & 1) ? xr : -hr)), yj = (float)(y + ((c & 2) ? vr : -vr));
