@@ -86,3 +86,16 @@ def test_edge_cases_against_host_division(ctx):
     assert inside.sum() > 60000 and (~inside).sum() > 1000
     u, v = ctx.selftest_divide(X[inside], Y[inside], Z[inside])
     assert _same(u, u_ref[inside]).all() and _same(v, v_ref[inside]).all()
+
+
+def test_cost_tail_square_root_is_correctly_rounded_for_every_mantissa():
+    """sqrt_rsq_exact (tsar_device_math.h: v_rsq_f32 + one fused residual correction, the square root of pmCost's tail in both
+    arithmetic modes) against sqrtf on the device: every mantissa of two adjacent binades — both exponent parities, 2^24 inputs, the
+    enumeration the claim rests on — and 2^24 random inputs per seed with exponents across its range; the control (no correction
+    step) must report mismatches, or the comparison would discriminate nothing"""
+    m = api.Matcher()
+    assert m.selftest_sqrt(0) == 0
+    for seed in (1, 2, 3):
+        assert m.selftest_sqrt(1, seed) == 0
+    assert m.selftest_sqrt(2) > 1000
+    m.close()

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse", "tsar_fuse_ctx",
     "tsar_host_alloc", "tsar_host_free", "tsar_device_alloc", "tsar_device_free", "tsar_device_write", "tsar_peer_copy", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
-    "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sweep_census",
+    "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sqrt", "tsar_selftest_sweep_census",
 ]
 
 _lib = None
@@ -141,6 +141,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming), C.c_int, C.POINTER(C.c_int)]
     L.tsar_selftest_divide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     L.tsar_selftest_sweep_census.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.tsar_selftest_sqrt.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tsar_selftest_divide_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
@@ -343,6 +344,12 @@ class Matcher:
         u, v = np.empty_like(X), np.empty_like(X)
         self._chk(self.L.tsar_selftest_divide(self._ctx, _ptr(X)[0], _ptr(Y)[0], _ptr(Z)[0], X.size, _ptr(u)[0], _ptr(v)[0], int(ieee) if mode is None else mode))
         return u, v
+
+    def selftest_sqrt(self, mode: int, seed: int = 0) -> int:
+        """mismatches of the cost tail's square root (sqrt_rsq_exact) against sqrtf on the device; mode 0: all 2^24 mantissa / parity cases"""
+        bad = C.c_uint64(0)
+        self._chk(self.L.tsar_selftest_sqrt(self._ctx, mode, seed, C.byref(bad)))
+        return bad.value
 
     def selftest_sweep_census(self, colour: int) -> dict:
         out = (C.c_uint64 * 8)()

@@ -219,12 +219,24 @@ DEVFN float multiview_cost(const DevScene* __restrict__ sc, const typename TileO
             static_assert(V == 0, "unknown tap-loop variant");
             c = view_cost_generic<HR, STRICT, QUAD, BLK>(sc, sc->view[vi], tile, tw, own, wts, pr, x, y, n4);
         }
-        if (c < TSAR_MAXCOST) valid++; else c = TSAR_MAXCOST;
-        if (c <= cmin) { cmin = c; bv = vi; }   // last view attaining the minimum (gipuma.cu:506-510)
+        // if (c < MAXCOST) valid++; else c = MAXCOST;  if (c <= cmin) { cmin = c; bv = vi; } (last view attaining the minimum,
+        // gipuma.cu:506-510) — written on sign bits instead of lane masks (v_cndmask / v_addc issue at several times a v_fma's cost
+        // here): c is a finite cost or MAXCOST, never NaN, so c < MAXCOST  <=>  c - MAXCOST < 0 and c > cmin  <=>  cmin - c < 0
+        // (v_min / v_max by asm: fminf / fmaxf make the compiler canonicalise each operand first, a v_max_f32 x, x per call; the
+        // operands here are never NaN)
+        auto vmin = [](float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        auto vmax = [](float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        c = vmin(c, TSAR_MAXCOST);
+        valid -= (int32_t)__float_as_uint(c - TSAR_MAXCOST) >> 31;
+        {
+            const uint32_t worse = (uint32_t)((int32_t)__float_as_uint(cmin - c) >> 31);      // all ones where c > cmin (cmin = +inf at first: inf - c > 0)
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bv) : "v"(worse), "v"(bv), "s"(vi));       // (worse & bv) | (~worse & vi): the compiler turns the C form back into v_cmp + v_cndmask
+            cmin = vmin(cmin, c);
+        }
         float v = c;
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const float lo = fminf(best[k], v), hi = fmaxf(best[k], v);
+            const float lo = vmin(best[k], v), hi = vmax(best[k], v);
             best[k] = lo;
             v = hi;
         }

@@ -296,6 +296,8 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
     const float var_src = sum_src_src - sum_src * sum_src;
     if (var_src < 1e-5f) return TSAR_MAXCOST;
     const float covar = sum_ref_src - pr.mean_ref * sum_src;
-    const float vrs = sqrtf(pr.var_ref * var_src);
+    // both variances are >= 1e-5 here and at most 255^2 (8-bit imagery): their product lies inside sqrt_rsq_exact's range by
+    // construction, so the correctly rounded root needs no guard (and none of the six v_cndmask of the compiler's sqrtf)
+    const float vrs = sqrt_rsq_exact(pr.var_ref * var_src);
     return fmaxf(0.0f, fminf(TSAR_MAXCOST, 1.0f - covar / vrs));
 }

@@ -60,6 +60,30 @@ __global__ __launch_bounds__(ST_BLOCK) void divide_random_kernel(uint32_t per_th
     }
 }
 
+// sqrt_rsq_exact against sqrtf.  mode 0: EVERY mantissa in the binades [1, 2) and [2, 4) — both exponent parities, 2^24 inputs: the
+// rounding of Markstein's correction depends on the mantissa and the parity only while every intermediate stays normal; mode 1:
+// 2^24 random inputs with exponents across the guard range [2^-100, 2^100] (the scaling argument, sampled).
+__global__ __launch_bounds__(ST_BLOCK) void sqrt_enumerate_kernel(int mode, uint32_t seed_lo, uint32_t seed_hi, unsigned long long* out) {
+    const uint32_t i = blockIdx.x * ST_BLOCK + threadIdx.x;            // 2^24 threads
+    float x;
+    if (mode == 0 || mode == 2) x = __uint_as_float(0x3f800000u + i);   // 1.0 .. 4.0 - ulp
+    else {
+        const Rand4 rn = philox_uniform4(i, 0u, 0x5a17u, seed_lo, seed_hi);
+        const uint32_t m = (uint32_t)(rn.u[0] * 16777216.0f) - 1u, e = 27u + (uint32_t)(rn.u[1] * 200.0f) % 200u;   // 2^-100 .. 2^99
+        x = __uint_as_float((e << 23) | (m & 0x7fffffu));
+    }
+    // mode 2: the control — x v_rsq_f32(x) WITHOUT the correction must differ somewhere, or the comparison discriminates nothing
+    const float got = mode == 2 ? x * __builtin_amdgcn_rsqf(x) : sqrt_rsq_exact(x);
+    uint32_t bad = __float_as_uint(got) != __float_as_uint(sqrtf(x));
+    for (int o = 32; o; o >>= 1) bad += __shfl_down(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&out[0], (unsigned long long)bad);
+}
+int launch_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, unsigned long long* dcounts) {
+    hipLaunchKernelGGL(sqrt_enumerate_kernel, dim3((1u << 24) / ST_BLOCK), dim3(ST_BLOCK), 0, ctx->stream, mode, (uint32_t)seed, (uint32_t)(seed >> 32), dcounts);
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
 int launch_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u, float* v, int ieee) {
     hipLaunchKernelGGL(divide_arrays_kernel, dim3((unsigned)((n + ST_BLOCK - 1) / ST_BLOCK)), dim3(ST_BLOCK), 0, ctx->stream, X, Y, Z, n, u, v, ieee);
     TSAR_HIP_TRY(ctx, hipGetLastError());

@@ -370,10 +370,25 @@ static int probe_exact_divide(tsar_ctx* ctx) {
     ctx->exact_div_probe = total == 0 ? 1 : -1;
     return ctx->exact_div_probe;
 }
+// The same for the square root of the cost's tail (sqrt_rsq_exact, tsar_device_math.h), which BOTH arithmetic modes run on 8-bit
+// imagery: all 2^24 mantissa / exponent-parity cases against sqrtf on the device, once per context (~0.2 ms).
+static int probe_exact_sqrt(tsar_ctx* ctx) {
+    if (ctx->exact_sqrt_probe != 0) return ctx->exact_sqrt_probe;
+    uint64_t bad = 0;
+    if (tsar_selftest_sqrt(ctx, 0, 0, &bad) != TSAR_OK) return 0;
+    ctx->exact_sqrt_probe = bad == 0 ? 1 : -1;
+    return ctx->exact_sqrt_probe;
+}
 
 extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
     CHECK_CTX(ctx);
     if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
+    {
+        const int ps = probe_exact_sqrt(ctx);
+        if (ps == 0) return TSAR_ERR_HIP;
+        if (ps < 0) return fail(ctx, TSAR_ERR_HIP, "this device's v_rsq_f32 does not give correctly rounded square roots through the one-correction sequence of the cost's tail "
+                                                   "(tsar_selftest_sqrt found mismatches against sqrtf): refused rather than run with costs that differ from the oracle's");
+    }
     if (ctx->params.flags & TSAR_FLAG_STRICT_DIV) {
         const int pr = probe_exact_divide(ctx);
         if (pr == 0) return TSAR_ERR_HIP;
@@ -937,6 +952,22 @@ extern "C" int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint
     scratch.release();
     *mismatches_out = hc[0];
     if (outside_guard_out) *outside_guard_out = hc[1];
+    return rc;
+}
+extern "C" int tsar_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, uint64_t* mismatches_out) {
+    CHECK_CTX(ctx);
+    if (mode < 0 || mode > 2 || !mismatches_out) return fail(ctx, TSAR_ERR_INVALID, "mode in 0..2");
+    ScratchScope scratch(ctx);
+    unsigned long long* dc = (unsigned long long*)scratch.alloc(sizeof(unsigned long long));
+    if (!dc) { scratch.release(); return fail(ctx, TSAR_ERR_NOMEM, "device allocation failed"); }
+    unsigned long long hc = 0;
+    int rc = TSAR_OK;
+    if (hipMemsetAsync(dc, 0, sizeof hc, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemsetAsync failed");
+    if (rc == TSAR_OK) rc = launch_selftest_sqrt(ctx, mode, seed, dc);
+    if (rc == TSAR_OK && hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemcpyAsync failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
+    scratch.release();
+    *mismatches_out = hc;
     return rc;
 }
 extern "C" int tsar_selftest_sweep_census(tsar_ctx* ctx, int colour, uint64_t* out8) {

@@ -117,6 +117,7 @@ struct tsar_ctx {
     int n_regions = 0;
     float *region_text = nullptr, *region_size = nullptr;
     float4* region_n4 = nullptr;
+    int exact_sqrt_probe = 0;    // the cost tail's square root (sqrt_rsq_exact) on THIS device: 0 not probed yet, 1 holds, -1 failed
     int exact_div_probe = 0;     // strict mode's short exact division on THIS device: 0 not probed yet, 1 holds, -1 failed (probe_exact_divide)
     int sweeps_done = 0;         // RNG stream counter
     const float* final_text = nullptr;   // device lines->text while tsar_pm_iterate_final runs (the kernels' `final` mode), else null
@@ -235,6 +236,7 @@ int launch_lrdiff(tsar_ctx* ctx);
 int launch_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u, float* v, int ieee);   // selftest_kernels.hip
 int launch_sweep_census(tsar_ctx* ctx, int colour, unsigned long long* dout);
 int launch_selftest_divide_random(tsar_ctx* ctx, int log2_pairs, uint64_t seed, int mode, int guarded, unsigned long long* dcounts);
+int launch_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, unsigned long long* dcounts);
 int launch_update_scale(tsar_ctx* ctx);
 int launch_fake_depth(tsar_ctx* ctx);
 int launch_split_out4(tsar_ctx* ctx, float* depth, float* normal3);

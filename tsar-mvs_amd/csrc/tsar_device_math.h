@@ -79,6 +79,21 @@ DEVFN void persp_divide_exact(float X, float Y, float Z, float& u, float& v) {
     }
 }
 
+// sqrtf of the matching cost's tail (pmCost gipuma.cu:289-297: 1 - covar / sqrtf(var_ref * var_src)), correctly rounded like the oracle's
+// sqrtf but without the compiler's sequence (v_sqrt_f32 + two residual tests + denormal scaling: ~17 instructions, six of them
+// v_cndmask): s = x y and h = y / 2 from y = v_rsq_f32(x), one fused residual correction s' = s + (x - s s) h — Markstein's square
+// root.  That s' is the correctly rounded root is not argued but ENUMERATED, like the divide's: for x in two adjacent binades (every
+// mantissa, both exponent parities: 2^24 inputs) and sampled across the range, tsar_selftest_sqrt compares it with sqrtf on the device
+// (0 mismatches; tests/test_gpu_divide.py, and tsar_set_views re-runs the enumeration once per context).  Operand range [2^-100,
+// 2^100] (no intermediate leaves the normal range); the 8-bit tap loops need no guard: both variances are >= 1e-5 where this is
+// reached and at most 255^2.  (Measured: +0.1 % on the bench, like the mask-free bookkeeping of multiview_cost +0.4 %; a guarded
+// form with the short exact division on top LOST 1.1 % to its two wave-uniform branches: profiles/r04/README.md section 5.)
+DEVFN float sqrt_rsq_exact(float x) {                             // x inside [2^-100, 2^100]
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y, h = 0.5f * y;
+    return fma_(fma_(-s, s, x), h, s);
+}
+
 // Philox4x32-10 counter-based generator: stateless (0 B/pixel; the reference keeps 48 B/pixel of
 // XORWOW state and re-seeds it from clock64() in every kernel, gipuma.cu:700,1077,1714).
 struct Rand4 {
