@@ -315,6 +315,18 @@ int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint64_t seed, 
  * evaluations the wave-uniform hypothesis loop of the sweep kernel runs, against what lane-local candidate queues would run
  * (gipuma.cu:553-555 early-outs; selftest_kernels.hip documents the eight counters). */
 int tsar_selftest_sweep_census(tsar_ctx* ctx, int colour, uint64_t* out8);
+/* One stage of tsar_slic on caller-supplied HOST arrays, so that a test can hold every SLIC kernel to the outputs of the reference's
+ * own per-pixel functions (gSLICr_seg_engine_shared.h:7-204, host-compiled from the reference where it lies: tests/golden/slic_ref.npz).
+ * Centres are 32-byte records laid out like the reference's spixel_info (gSLICr_spixel_info.h:11-17: center 2 f32, color_info
+ * 4 f32, id i32, no_pixels i32).  Uses s->spixel_size, s->coh_weight, s->color_space.
+ *   stage 0  Cvt_Img_Space:            in0 = bgra u8[h*w*4]                          inout = float4[h*w]         (out)
+ *   stage 1  Init_Cluster_Centers:     in0 = float4[h*w]                             inout = centres[mw*mh]      (out)
+ *   stage 2  Find_Center_Association:  in0 = float4[h*w], in1 = centres[mw*mh]       inout = labels i32[h*w]     (in: previous, out)
+ *   stage 3  Update_Cluster_Center + Finalize_Reduction_Result (mw = w / S, mh = h / S):
+ *                                      in0 = float4[h*w], in1 = labels i32[h*w]      inout = centres[mw*mh]      (out)
+ *   stage 4  Enforce_Connectivity, one pass: in0 = labels i32[h*w]                   inout = labels i32[h*w]     (out) */
+int tsar_selftest_slic_stage(tsar_ctx* ctx, int stage, int w, int h, int mw, int mh, const tsar_slic_settings* s, const void* in0,
+                             const void* in1, void* inout);
 
 #ifdef __cplusplus
 }

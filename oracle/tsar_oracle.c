@@ -6,12 +6,17 @@
  * product (libtsar_hip.so, tsar_mvs_amd/); only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may use it, and only as the checker / the reported CPU baseline.
  *
- * PARITY UNPINNED.  The reference ships no tests, golden vectors or sample outputs and
- * cannot be built in this image (it needs nvcc, the CUDA headers/runtime, cuRAND and OpenCV; none
- * are present and stand-ins for them are not allowed).  This file is therefore pinned only by
- * analytic known answers authored in tests/ (a plane that truly generated the images scores ~0,
- * homography of a fronto-parallel plane is the expected translation, plane<->depth round trips,
- * etc.), not by outputs of the reference itself.
+ * PARITY: UNPINNED for everything restated from gipuma.cu / main.cpp.  The reference ships no tests, golden vectors or sample
+ * outputs, and those two files cannot be built in this image (they need nvcc, the CUDA headers/runtime, cuRAND and
+ * OpenCV; none are present and stand-ins for them are not allowed).  This file is therefore pinned by analytic known answers
+ * authored in tests/ (a plane that truly generated the images scores ~0, homography of a fronto-parallel plane is the expected
+ * translation, plane<->depth round trips, etc.), not by outputs of gipuma.cu.
+ * PINNED BY THE REFERENCE ITSELF are the two pieces of it that a host compiler takes as they stand (oracle/Makefile `ref`,
+ * built from the sources where they lie; outputs recorded by tests/golden/make_slic_ref_golden.py):
+ *   - config.h:60-240, the 3x3 array macros getHomography_cu is made of (outer_product, matdivide, matmatsub2, matmul_cu,
+ *     matvecmul): mat3mul / mat3vec / homography below, built with -DORC_NO_FMA, reproduce them BIT FOR BIT
+ *     (tests/test_reference_macros_golden.py) — operand order and the element-wise division by d are the reference's;
+ *   - gSLICr_Lib/engines/gSLICr_seg_engine_shared.h:7-204 — see tsar_oracle_slic.c.
  *
  * Each function cites the reference lines it restates.  Where the reference is non-deterministic
  * or undefined, the deterministic semantics chosen are:
@@ -37,6 +42,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* -DORC_NO_FMA (oracle/Makefile: libtsar_oracle_nofma.so) writes every fmaf(a, b, c) of S4 as a * b + c, two roundings: the build
+ * that can be held BIT FOR BIT to the reference's own config.h macros compiled by g++ without contraction
+ * (tests/test_reference_macros_golden.py) — it pins which operands meet in which order; where nvcc fuses is S4's assumption. */
+#ifdef ORC_NO_FMA
+#define fmaf(a, b, c) ((a) * (b) + (c))
+#endif
 
 #define ORC_MAX_VIEWS 64
 #define ORC_MAXCOST 2.0f
@@ -311,6 +323,14 @@ static inline void homography(const orc_camera *ref, const orc_camera *to, const
     mat3mul(to->K, T, H);
 }
 void orc_homography(const orc_state *s, int view, const float *n4, float *H) { homography(&s->cam[0], &s->cam[view], n4, H); }
+/* the same on bare arrays (tests/test_reference_macros_golden.py: against the reference's own config.h macros compiled on the host) */
+void orc_homography_arrays(const float *K1_inv, const float *K2, const float *R, const float *t, const float *n4, float *H) {
+    orc_camera ref, to;
+    memcpy(ref.Kinv, K1_inv, 36); memcpy(to.K, K2, 36); memcpy(to.R, R, 36); memcpy(to.t, t, 12);
+    homography(&ref, &to, n4, H);
+}
+void orc_mat3mul(const float *a, const float *b, float *o) { mat3mul(a, b, o); }
+void orc_mat3vec(const float *m, const float *v, float *o) { mat3vec(m, v, o); }
 
 /* S7 (1): v_rcp_f32 from the device's mantissa table; the exponent and sign are exact */
 static inline float rcp_gpu(const orc_state *s, float x) {

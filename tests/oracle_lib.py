@@ -16,6 +16,21 @@ _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
 
 
+ORACLE_NOFMA_SO = os.path.join(ORACLE_DIR, "libtsar_oracle_nofma.so")
+
+
+def nofma_lib():
+    """tsar_oracle.c built with every fmaf() as multiply-then-add (-DORC_NO_FMA): the form that can be compared bit for bit with
+    the reference's own config.h macros compiled without contraction (tests/test_reference_macros_golden.py)"""
+    src = os.path.join(ORACLE_DIR, "tsar_oracle.c")
+    if not os.path.exists(ORACLE_NOFMA_SO) or os.path.getmtime(src) > os.path.getmtime(ORACLE_NOFMA_SO):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libtsar_oracle_nofma.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(ORACLE_NOFMA_SO)
+    for n in ("orc_homography_arrays", "orc_mat3mul", "orc_mat3vec"):
+        getattr(L, n).restype = None
+    return L
+
+
 def build_oracle(force: bool = False) -> str:
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".c")]
     stale = (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
@@ -74,8 +89,25 @@ def lib():
         L.orc_region_planes.argtypes = [C.c_void_p]
         L.orc_ransac_points.restype = C.c_int
         L.orc_ransac_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
-        L.orc_cbrtf.restype = C.c_float
-        L.orc_cbrtf.argtypes = [C.c_float]
+        L.orc_pow_third.restype = C.c_float
+        L.orc_pow_third.argtypes = [C.c_float]
+        L.orc_pow_third_check.restype = None
+        L.orc_pow_third_check.argtypes = [C.c_void_p]
+        L.orc_slic_distance.restype = C.c_float
+        L.orc_slic_distance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float]
+        L.orc_slic_blocks_per_spixel.restype = C.c_int
+        L.orc_slic_blocks_per_spixel.argtypes = [C.c_int]
+        for n, at in (("orc_slic_convert", [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+                      ("orc_slic_init_centers", [C.c_void_p, C.c_void_p] + [C.c_int] * 5),
+                      ("orc_slic_find_association", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float]),
+                      ("orc_slic_partials", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
+                      ("orc_slic_finalize", [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+                      ("orc_slic_update_centers", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
+                      ("orc_slic_connectivity", [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+                      ("orc_slic_from_lab", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+                      ("orc_homography_arrays", [C.c_void_p] * 6), ("orc_mat3mul", [C.c_void_p] * 3), ("orc_mat3vec", [C.c_void_p] * 3)):
+            getattr(L, n).restype = None
+            getattr(L, n).argtypes = at
         L.orc_slic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_refine_steps.restype = C.c_int
         L.orc_refine_steps.argtypes = [C.c_void_p]
@@ -348,8 +380,93 @@ def ransac_points(pts, region_size, seed=0, region=0, flags=0):
     return plane, int(best)
 
 
-def cbrtf(x):
-    return float(lib().orc_cbrtf(C.c_float(x)))
+def pow_third(x):
+    """x^(1.0f / 3.0f) as rgb2CIELab's pow() is restated (oracle/tsar_oracle_slic.c): correctly rounded to fp32"""
+    return float(lib().orc_pow_third(C.c_float(x)))
+
+
+def pow_third_check():
+    """(evaluations, mismatches against powl rounded to fp32, evaluations where this host's powf differs from that) over every
+    argument an 8-bit colour can hand to rgb2CIELab's pow()"""
+    out = np.zeros(3, np.int64)
+    lib().orc_pow_third_check(_p(out))
+    return tuple(int(v) for v in out)
+
+
+# the reference's spixel_info (gSLICr_spixel_info.h:11-17) = the oracle's `spixel`
+SPIXEL_DTYPE = np.dtype([("center", np.float32, 2), ("color", np.float32, 4), ("id", np.int32), ("n", np.int32)])
+
+
+def slic_convert(bgra, color_space=0):
+    px = np.ascontiguousarray(bgra, np.uint8).reshape(-1, 4)
+    out = np.zeros((px.shape[0], 4), np.float32)
+    lib().orc_slic_convert(_p(px), _p(out), px.shape[0], color_space)
+    return out
+
+
+def slic_init_centers(lab, mw, mh, S):
+    lab = np.ascontiguousarray(lab, np.float32)
+    h, w = lab.shape[:2]
+    out = np.zeros(mw * mh, SPIXEL_DTYPE)
+    lib().orc_slic_init_centers(_p(lab), _p(out), w, h, mw, mh, S)
+    return out
+
+
+def slic_distance(pix, x, y, centre, weight, norm_xy):
+    pix = np.ascontiguousarray(pix, np.float32)
+    c = np.ascontiguousarray(centre)
+    return float(lib().orc_slic_distance(_p(pix), int(x), int(y), _p(c), C.c_float(weight), C.c_float(norm_xy)))
+
+
+def slic_find_association(lab, centres, mw, mh, S, weight, labels_before=None):
+    lab = np.ascontiguousarray(lab, np.float32)
+    h, w = lab.shape[:2]
+    labels = np.zeros((h, w), np.int32) if labels_before is None else np.ascontiguousarray(labels_before, np.int32).copy()
+    lib().orc_slic_find_association(_p(lab), _p(np.ascontiguousarray(centres)), _p(labels), w, h, mw, mh, S, C.c_float(weight))
+    return labels
+
+
+def slic_partials(lab, labels, S):
+    """what Update_Cluster_Center_device leaves in accum_map: blocks_per_spixel(S) records per superpixel"""
+    lab = np.ascontiguousarray(lab, np.float32)
+    h, w = lab.shape[:2]
+    mw, mh = w // S, h // S
+    nblk = lib().orc_slic_blocks_per_spixel(S)
+    out = np.zeros((mw * mh, nblk), SPIXEL_DTYPE)
+    lib().orc_slic_partials(_p(lab), _p(np.ascontiguousarray(labels, np.int32)), _p(out), w, h, mw, mh, S)
+    return out
+
+
+def slic_finalize(accum):
+    accum = np.ascontiguousarray(accum)
+    out = np.zeros(accum.shape[0], SPIXEL_DTYPE)
+    lib().orc_slic_finalize(_p(accum), _p(out), accum.shape[0], accum.shape[1])
+    return out
+
+
+def slic_update_centers(lab, labels, S):
+    lab = np.ascontiguousarray(lab, np.float32)
+    h, w = lab.shape[:2]
+    out = np.zeros((w // S) * (h // S), SPIXEL_DTYPE)
+    lib().orc_slic_update_centers(_p(lab), _p(np.ascontiguousarray(labels, np.int32)), _p(out), w, h, w // S, h // S, S)
+    out["id"] = np.arange(out.size)
+    return out
+
+
+def slic_connectivity(labels):
+    labels = np.ascontiguousarray(labels, np.int32)
+    out = np.zeros_like(labels)
+    lib().orc_slic_connectivity(_p(labels), _p(out), labels.shape[1], labels.shape[0])
+    return out
+
+
+def slic_from_lab(lab, S=20, iters=5, weight=5.0, connectivity=0):
+    lab = np.ascontiguousarray(lab, np.float32)
+    h, w = lab.shape[:2]
+    labels = np.zeros((h, w), np.int32)
+    centres = np.zeros((w // S) * (h // S), SPIXEL_DTYPE)
+    lib().orc_slic_from_lab(_p(lab), w, h, S, iters, C.c_float(weight), connectivity, _p(labels), _p(centres))
+    return labels, centres
 
 
 def rgb2lab(bgra):

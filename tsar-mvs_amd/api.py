@@ -57,6 +57,9 @@ class KernelTiming(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
 
+# the reference's spixel_info (gSLICr_spixel_info.h:11-17), the record of tsar_selftest_slic_stage's centre arrays
+SPIXEL_DTYPE = np.dtype([("center", np.float32, 2), ("color", np.float32, 4), ("id", np.int32), ("n", np.int32)])
+
 # every symbol include/tsar.h declares (tests check that the library exports exactly these)
 ABI_SYMBOLS = [
     "tsar_create", "tsar_destroy", "tsar_last_error", "tsar_version", "tsar_get_stream", "tsar_synchronize",
@@ -67,7 +70,7 @@ ABI_SYMBOLS = [
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse", "tsar_fuse_ctx",
     "tsar_host_alloc", "tsar_host_free", "tsar_device_alloc", "tsar_device_free", "tsar_device_write", "tsar_peer_copy", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
-    "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sqrt", "tsar_selftest_sweep_census",
+    "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sqrt", "tsar_selftest_sweep_census", "tsar_selftest_slic_stage",
 ]
 
 _lib = None
@@ -143,6 +146,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_selftest_sweep_census.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
     L.tsar_selftest_sqrt.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tsar_selftest_divide_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tsar_selftest_slic_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SlicSettings), C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -362,6 +366,37 @@ class Matcher:
         bad, out = C.c_uint64(0), C.c_uint64(0)
         self._chk(self.L.tsar_selftest_divide_random(self._ctx, log2_triples, seed, mode, int(guarded), C.byref(bad), C.byref(out)))
         return bad.value, out.value
+
+    # one stage of tsar_slic on host arrays (include/tsar.h tsar_selftest_slic_stage); centres are SPIXEL_DTYPE records
+    def _slic_stage(self, stage, w, h, mw, mh, settings, in0, in1, inout):
+        p1 = _ptr(in1)[0] if in1 is not None else None
+        self._chk(self.L.tsar_selftest_slic_stage(self._ctx, stage, w, h, mw, mh, C.byref(settings), _ptr(in0)[0], p1, _ptr(inout)[0]))
+        return inout
+
+    def slic_convert(self, bgra, color_space=0):
+        img = np.ascontiguousarray(bgra, np.uint8).reshape(-1, 4)
+        return self._slic_stage(0, img.shape[0], 1, 0, 0, SlicSettings(20, 0, 5.0, 0, color_space), img, None, np.zeros((img.shape[0], 4), np.float32))
+
+    def slic_init_centers(self, lab, mw, mh, S):
+        lab = np.ascontiguousarray(lab, np.float32)
+        h, w = lab.shape[:2]
+        return self._slic_stage(1, w, h, mw, mh, SlicSettings(S, 0, 5.0, 0, 0), lab, None, np.zeros(mw * mh, SPIXEL_DTYPE))
+
+    def slic_find_association(self, lab, centres, mw, mh, S, weight, labels_before=None):
+        lab = np.ascontiguousarray(lab, np.float32)
+        h, w = lab.shape[:2]
+        labels = np.zeros((h, w), np.int32) if labels_before is None else np.ascontiguousarray(labels_before, np.int32).copy()
+        return self._slic_stage(2, w, h, mw, mh, SlicSettings(S, 0, weight, 0, 0), lab, np.ascontiguousarray(centres), labels)
+
+    def slic_update_centers(self, lab, labels, S):
+        lab = np.ascontiguousarray(lab, np.float32)
+        h, w = lab.shape[:2]
+        return self._slic_stage(3, w, h, w // S, h // S, SlicSettings(S, 0, 5.0, 0, 0), lab, np.ascontiguousarray(labels, np.int32), np.zeros((w // S) * (h // S), SPIXEL_DTYPE))
+
+    def slic_connectivity(self, labels):
+        labels = np.ascontiguousarray(labels, np.int32)
+        h, w = labels.shape
+        return self._slic_stage(4, w, h, 0, 0, SlicSettings(20, 0, 5.0, 0, 0), labels, None, np.zeros((h, w), np.int32))
 
     def getview(self):
         self._chk(self.L.tsar_getview(self._ctx))
