@@ -48,7 +48,8 @@ def traffic_from_profiles(args=None):
     read hardware counters itself).  FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE is doubled as
     MI355X_MICROARCH.md §HBM prescribes for gfx950 (it tallies 128-B requests at 64 B) — uncalibrated for
     this kernel's 4-byte gathers, so read it as an upper bound.  Converged launches only (the first two of a run
-    start from random planes).  Returns None when no profile is committed."""
+    start from random planes).  Returns {"bytes", "source"} — source = the latest profiles/rNN that holds both passes, named in
+    the line as roofline.traffic_source — or None when no profile is committed."""
     import csv
     import glob
     if args is not None and (args.width, args.height, args.views, args.iters, args.box, args.n_best) != (6048, 4032, 10, 8, 11, 1):
@@ -56,17 +57,18 @@ def traffic_from_profiles(args=None):
     prof = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r*")) if os.path.isdir(d))
     if not prof:
         return None
-    vals = {}
+    prof = [d for d in prof if all(os.path.exists(os.path.join(d, f"pmc_{n}_size_sweep.csv")) for n in ("fetch", "write"))]
+    if not prof:
+        return None
+    vals = {"source": os.path.relpath(prof[-1], ROOT)}
     for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         f = os.path.join(prof[-1], f"pmc_{name}_size_sweep.csv")
-        if not os.path.exists(f):
-            return None
         rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "pm_sweep" in r["Kernel_Name"]]
         rows = rows[2:] if len(rows) > 2 else rows
         if not rows:
             return None
         vals[name] = sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0
-    return 2.0 * vals["fetch"] + vals["write"]
+    return {"bytes": 2.0 * vals["fetch"] + vals["write"], "source": vals["source"]}
 
 
 def available_cpus() -> int:
@@ -212,11 +214,10 @@ def strict_mode_record(args, sc, local_rank, fast_maps=None):
 
 def self_launch(args) -> int:
     """`python bench.py --gpus N` typed without a launcher (N > 1): start the N ranks under torch.distributed.run as a CHILD process
-    and hand on its exit code; rank 0's JSON line reaches stdout through the inherited descriptor.  Nothing in this parent has
-    touched the GPU (no HIP call, no torch.cuda initialisation: counting devices does not initialise them on this image), so the
-    child ranks are the only GPU processes.  Replaces the reference's one-process-per-view shell loop (scripts/courtyard.sh:29-48).
-    With fewer devices than ranks (a rehearsal on a smaller box) the ranks share devices over the gloo transport, and the line's
-    n_gpus says how many devices really ran."""
+    and hand on its exit code; rank 0's JSON line reaches stdout through the inherited descriptor.  The parent makes NO torch.cuda /
+    HIP call at all (tests/test_driver_gloo.py replaces torch.cuda with an object that raises on any attribute): the ranks
+    themselves decide between RCCL and the gloo rehearsal transport (choose_backend), so the child ranks are the only processes
+    that ever initialise the runtime.  Replaces the reference's one-process-per-view shell loop (scripts/courtyard.sh:29-48)."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -224,15 +225,40 @@ def self_launch(args) -> int:
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if torch.cuda.device_count() < args.gpus and "TSAR_BENCH_BACKEND" not in env:
-        print(f"bench.py: {torch.cuda.device_count()} device(s) for {args.gpus} ranks: rehearsal over gloo, ranks share devices", file=sys.stderr)
-        env["TSAR_BENCH_BACKEND"] = "gloo"
     argv = list(sys.argv[1:])
     if "--verify-gather" not in argv:
         argv.append("--verify-gather")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd, env=env)
+
+
+def choose_backend(world: int, n_devices: int, env=os.environ) -> str:
+    """Decided inside every rank (all ranks of a node see the same device count, so they agree): RCCL ("nccl") with one device per
+    rank; with fewer devices than ranks — a rehearsal on a smaller box — the ranks share devices over gloo and the line says so
+    (backend, devices, n_gpus = distinct devices).  TSAR_BENCH_BACKEND overrides."""
+    forced = env.get("TSAR_BENCH_BACKEND")
+    if forced:
+        return forced
+    return "nccl" if n_devices >= world else "gloo"
+
+
+def device_identity(index: int) -> dict:
+    """what this rank's device IS, for the proof-of-ranks fields of the line: marketing name, gfx arch, and the PCI address / UUID
+    that tell two devices apart (whatever of them this torch build exposes)"""
+    p = torch.cuda.get_device_properties(index)
+    ident = {"index": index, "name": p.name, "arch": getattr(p, "gcnArchName", None)}
+    if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        ident["pci"] = "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    if hasattr(p, "uuid"):
+        ident["uuid"] = str(p.uuid)
+    ident["visible"] = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    return ident
+
+
+def device_key(ident: dict):
+    """two ranks ran on the same physical device iff their keys are equal"""
+    return ident.get("pci") or ident.get("uuid") or (ident.get("visible"), ident["index"])
 
 
 def main():
@@ -270,8 +296,10 @@ def main():
     dist = None
     # TSAR_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks
     # (ranks share devices, results are staged through host memory for the gather); never used for a reported number.
-    backend = os.environ.get("TSAR_BENCH_BACKEND", "nccl")
+    backend = choose_backend(world, torch.cuda.device_count())
     if backend != "nccl":
+        if world > 1 and rank == 0 and "TSAR_BENCH_BACKEND" not in os.environ:
+            print(f"bench.py: {torch.cuda.device_count()} device(s) for {world} ranks: rehearsal over gloo, ranks share devices", file=sys.stderr)
         local_rank %= max(torch.cuda.device_count(), 1)
     # TSAR_BENCH_FORCE_DIST=1: also take the collective path with ONE rank (torch.distributed.run --nproc-per-node 1): the RCCL
     # communicator, the asynchronous gather, the barrier and the all-reduce then run on real hardware even on a one-GPU box
@@ -354,13 +382,20 @@ def main():
         step()
     drain()                                           # every gather has landed on rank 0
     torch.cuda.synchronize()
+    dt_before_barrier = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dt_own = dt_before_barrier                        # this rank's own K steps + its gathers, before it waited for the others
+    ranks_info = [{"rank": rank, "local_rank": local_rank, "backend": backend if dist is not None else "none", "device": device_identity(local_rank),
+                   "ms_per_step": dt_own / args.steps * 1e3}]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        everyone_info = [None] * world
+        dist.all_gather_object(everyone_info, ranks_info[0])
+        ranks_info = everyone_info
 
     timing = {} if args.no_kernel_timing else m.kernel_timing()
     # sanity on the product of the timed region (not part of the metric): converged depth vs the analytic scene
@@ -383,7 +418,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * w * h * args.steps / dt / 1e6
         line = {
-            "metric": "depthmap Mpixels/sec (ETH3D full-res, 8 iters)", "value": value, "unit": "Mpix/s", "n_gpus": world if backend == "nccl" else min(world, torch.cuda.device_count()),
+            "metric": "depthmap Mpixels/sec (ETH3D full-res, 8 iters)", "value": value, "unit": "Mpix/s", "n_gpus": len({device_key(r["device"]) for r in ranks_info}),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ETH3D-size view {w}x{h}, 1 ref + {args.views} src views, {args.iters} PatchMatch iters, box {args.box}, n_best {args.n_best}; one ref view per GPU",
@@ -395,7 +430,8 @@ def main():
             avg_ms = total_ms / launches
             bytes_per_launch = alg_bytes_per_pixel_iteration(args.views) * (w * h / 2.0)   # one launch = one colour = W*H/2 pixel-iterations
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic_from_profiles(args),
+            traffic = traffic_from_profiles(args)
+            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                                 "kernel": "pm_sweep_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                                 "kernel_note": "two instantiations of the one kernel: <.., 250, 256> (gathers as global loads from the byte texture) for the first sweep launch of a view (random planes), <.., 2228474, 256> (structured buffer loads from the half-float difference texture, v_fma_mix_f32 blend) for the other 15; avg_launch_ms is the mean over all 16 per view = (A + 15 x B) / 16 of a rocprofv3 --stats summary",
                                 "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -404,6 +440,17 @@ def main():
             tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
             line["roofline"]["valu"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flops_per_launch": flops_per_launch}
             line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
+        # proof of ranks: what the transport saw, gathered from every rank (all_gather_object) — a SCALE line must show N ranks on
+        # N distinct devices over "nccl" (= RCCL); a rehearsal shows its shared device and "gloo".  per_rank_ms_per_step is each rank's
+        # own time for the K steps before the closing barrier: a straggler is visible here, behind the all-reduce MAX it is not.
+        keys = [device_key(r["device"]) for r in ranks_info]
+        line["ranks"] = world
+        line["backend"] = ranks_info[0]["backend"]
+        line["devices"] = [r["device"] for r in ranks_info]
+        line["distinct_devices"] = len(set(keys))
+        line["per_rank_ms_per_step"] = [round(r["ms_per_step"], 3) for r in ranks_info]
+        if dist is not None and backend == "nccl" and len(set(keys)) != world:
+            raise SystemExit(f"bench.py: {world} ranks over RCCL but only {len(set(keys))} distinct devices: {keys}")
         if gather_check is not None:
             line["gather_check"] = gather_check
         line["config"]["tolerance"] = None

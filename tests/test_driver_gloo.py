@@ -119,8 +119,9 @@ def test_async_double_buffered_gather_world_size_2():
 
 def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
     """`python bench.py --gpus N` typed without a launcher: bench.self_launch starts torch.distributed.run as a CHILD with the same
-    arguments (+ --verify-gather), rendezvous on 127.0.0.1, and — with fewer devices than ranks, as on this CPU container — the
-    gloo rehearsal transport; the parent touches no GPU.  (The launched ranks themselves are covered by tests/test_gpu_multirank.py.)"""
+    arguments (+ --verify-gather), rendezvous on 127.0.0.1.  The parent makes NO torch.cuda call — asserted by replacing torch.cuda
+    with an object that raises on any attribute — because the transport (RCCL, or gloo when ranks outnumber devices) is chosen
+    inside the ranks (bench.choose_backend).  (The launched ranks themselves are covered by tests/test_gpu_multirank.py.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -133,10 +134,14 @@ def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return 7
 
+    class NoCuda:
+        def __getattr__(self, name):
+            raise AssertionError("the launching parent touched torch.cuda." + name)
+
     monkeypatch.setattr(subprocess, "call", fake_call)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     monkeypatch.delenv("TSAR_BENCH_BACKEND", raising=False)
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    monkeypatch.setattr(bench.torch, "cuda", NoCuda())
 
     class A:
         gpus = 4
@@ -147,9 +152,25 @@ def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
     assert tail == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--verify-gather"]
-    assert seen["env"]["TSAR_BENCH_BACKEND"] == "gloo"       # 0 devices < 4 ranks: rehearsal transport
+    assert "TSAR_BENCH_BACKEND" not in seen["env"]           # not the parent's decision
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    # enough devices: the RCCL backend stays (no TSAR_BENCH_BACKEND forced)
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
-    bench.self_launch(A())
-    assert "TSAR_BENCH_BACKEND" not in seen["env"]
+
+
+def test_bench_backend_is_chosen_inside_the_ranks():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    assert bench.choose_backend(8, 8, env={}) == "nccl"      # one device per rank: RCCL
+    assert bench.choose_backend(2, 1, env={}) == "gloo"      # rehearsal: ranks share the device
+    assert bench.choose_backend(1, 1, env={}) == "nccl"
+    assert bench.choose_backend(2, 8, env={"TSAR_BENCH_BACKEND": "gloo"}) == "gloo"
+    # device keys: a PCI address or UUID tells devices apart; without either, the visible-devices string and index
+    a = {"index": 0, "name": "x", "pci": "0000:05:00"}
+    b = {"index": 0, "name": "x", "pci": "0000:15:00"}
+    assert bench.device_key(a) != bench.device_key(b)
+    assert bench.device_key({"index": 1, "name": "x", "visible": None}) != bench.device_key({"index": 0, "name": "x", "visible": None})
+    # the traffic figure names the profile directory it was read from
+    t = bench.traffic_from_profiles()
+    assert t is None or (t["source"].startswith("profiles/r") and t["bytes"] > 0)

@@ -57,6 +57,10 @@ def test_bench_two_ranks_gather_is_bit_exact(as_typed):
                           "--no-cpu-baseline", "--no-kernel-timing"] + ([] if as_typed else ["--verify-gather"]), as_typed=as_typed)
     assert line["gather_check"]["verified"] is True, line["gather_check"]
     assert line["gather_check"]["ranks_differ"] is True, line["gather_check"]     # each rank matched its own view
+    # proof of ranks: the one-device rehearsal says what it is — 2 ranks, 1 device, gloo — in the line itself
+    assert line["ranks"] == 2 and line["backend"] == "gloo" and line["distinct_devices"] == 1 and line["n_gpus"] == 1
+    assert len(line["devices"]) == 2 and all(d["name"] for d in line["devices"]) and line["devices"][0].get("pci", 0) == line["devices"][1].get("pci", 0)
+    assert len(line["per_rank_ms_per_step"]) == 2 and all(0 < t <= line["ms_per_step"] * 1.001 for t in line["per_rank_ms_per_step"])
     assert line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
     assert line["config"]["mode"] == "fast"
     # whole-job value = the pixels of both ranks over the max-over-ranks time
@@ -82,4 +86,6 @@ def test_bench_one_rank_through_rccl():
                       env_extra={"TSAR_BENCH_FORCE_DIST": "1"}, backend="nccl")
     assert line["gather_check"]["verified"] is True, line["gather_check"]
     assert line["n_gpus"] == 1 and line["steps"] == 3
+    assert line["ranks"] == 1 and line["backend"] == "nccl" and line["distinct_devices"] == 1 and len(line["per_rank_ms_per_step"]) == 1
+    assert "MI355" in line["devices"][0]["name"] or "gfx950" in str(line["devices"][0].get("arch"))
     assert line["config"]["frac_depth_within_1pct_of_gt"] > 0.5
