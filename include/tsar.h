@@ -306,7 +306,9 @@ int tsar_get_kernel_timing(tsar_ctx* ctx, tsar_kernel_timing* out, int cap, int*
 /* tsar_selftest_sqrt: the square root of the matching cost's tail (tsar_device_math.h sqrt_rsq_exact: v_rsq_f32 + one fused residual
  * correction instead of the compiler's IEEE sequence) against sqrtf on the device; mode 0 = every mantissa of two adjacent binades
  * (both exponent parities, 2^24 inputs: the enumeration), mode 1 = 2^24 random inputs with exponents across [2^-100, 2^100], mode 2 =
- * the control (the same inputs as mode 0 without the correction step: must report mismatches). */
+ * the control (the same inputs as mode 0 without the correction step: must report mismatches), mode 3 = 2^24 random mantissas spread over
+ * the 67 binades the cost tail's operands can reach ([1e-10, 4.3e9]).  tsar_set_views runs modes 0 and 3 once per context before it
+ * accepts 8-bit imagery, and REFUSES the views (TSAR_ERR_HIP) on a mismatch; there is no fallback to sqrtf. */
 int tsar_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, uint64_t* mismatches_out);
 int tsar_selftest_divide(tsar_ctx* ctx, const float* X, const float* Y, const float* Z, size_t n, float* u_out, float* v_out, int ieee);
 int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint64_t seed, int mode, int guarded, uint64_t* mismatches_out,

@@ -98,4 +98,22 @@ def test_cost_tail_square_root_is_correctly_rounded_for_every_mantissa():
     for seed in (1, 2, 3):
         assert m.selftest_sqrt(1, seed) == 0
     assert m.selftest_sqrt(2) > 1000
+    for seed in (4, 5):
+        assert m.selftest_sqrt(3, seed) == 0            # the production operand range [1e-10, 4.3e9], binade by binade (the per-context probe's second pass)
+    m.close()
+
+
+def test_float_imagery_contexts_are_not_gated_on_the_square_root_probe():
+    """only the 8-bit tap loops run sqrt_rsq_exact; a context fed non-integral images keeps sqrtf and must not run (or be refused by)
+    the probe: exact_sqrt_probe stays unprobed — observable as set_views succeeding with the probe's kernels absent from the timing"""
+    import numpy as np
+    from tsar_mvs_amd import synth
+    sc = synth.make_scene(96, 64, 2, seed=4)
+    m = api.Matcher()
+    m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max))
+    imgs = [im.numpy() + np.float32(0.25) for im in sc.images]           # not an 8-bit decode: the float tap loop
+    m.set_views(imgs, sc.K, sc.R, sc.t)
+    m.pm_init()
+    m.pm_iterate(1)
+    assert np.isfinite(m.get_plane()[1]).all()
     m.close()

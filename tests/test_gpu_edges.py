@@ -191,3 +191,88 @@ def test_perspective_divide_at_the_operand_guard(strict):
         scored += int((c_ref < 2.0).sum())
     assert scored > 0 and not orc.rcp_out_of_range
     m.close()
+
+
+# ---- the fast path's clamp-free decision from the window's centre and a bound on its extent (pm_tap_r5.h:52-71) -------------------
+def _rot(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    return (Rz @ Rx @ Ry).astype(np.float32)
+
+
+def _scene_rotated():
+    """the translations of _scene() plus small rotations, so that the homographies have perspective terms (H6, H7 != 0: the
+    bound's c = 5 (|H6| + |H7|) and |Xc| c terms are live) and the window's extent in the source image is not 5 pixels flat"""
+    imgs, K, R, t = _scene()
+    R = R.copy()
+    R[1], R[2], R[3] = _rot(0.04, 0.0, 0.0), _rot(0.0, -0.05, 0.01), _rot(-0.03, 0.02, -0.02)
+    t = t.copy()
+    t[3] = (0.07, -0.06, 0.02)
+    return imgs, K, R, t
+
+
+def _centre_extent_margins(Hm):
+    """the decision of pm_tap_r5.h:52-71 restated in numpy (fp32): per pixel, the four distances by which the window bound clears
+    (>= 0) or misses (< 0) the source image's clamp-free region; H is the 3x3 plane homography of one view"""
+    f32 = np.float32
+    Hm = np.asarray(Hm, f32).ravel()
+    ys, xs = np.mgrid[0:H, 0:W]
+    xc, yc = xs.astype(f32), ys.astype(f32)
+    Xc, Yc, Zc = Hm[0] * xc + Hm[1] * yc + Hm[2], Hm[3] * xc + Hm[4] * yc + Hm[5], Hm[6] * xc + Hm[7] * yc + Hm[8]
+    a, b, c = abs(Hm[0]) + abs(Hm[1]), abs(Hm[3]) + abs(Hm[4]), abs(Hm[6]) + abs(Hm[7])
+    Zmin = Zc - f32(5) * c
+    with np.errstate(all="ignore"):
+        r = f32(1) / (Zmin * Zc)
+        du, dv = (a * Zc + np.abs(Xc) * c) * f32(5) * r, (b * Zc + np.abs(Yc) * c) * f32(5) * r
+        uc, vc = Xc * Zmin * r, Yc * Zmin * r
+    ok = Zmin > 0
+    return [np.where(ok, m, -np.inf) for m in (uc - du - f32(1.5), vc - dv - f32(1.5), f32(W - 1) - f32(1.5) - (uc + du), f32(H - 1) - f32(1.5) - (vc + dv))]
+
+
+def test_fast_path_window_bound_walked_across_its_threshold_on_every_border():
+    """Fast mode decides per wave, from the window's centre and a rigorous bound on its extent, whether its taps need the clamp;
+    a wrong bound would send a border window down range-checked buffer loads that return silent zeros (or, in the global-load
+    form, outside the texture).  Planes of several slants are moved in depth so that, view by view, the source windows of the
+    border pixels sit from 0 to more than 3 extents inside each of the four borders — the numpy restatement of the decision
+    asserts that pixels land within a quarter pixel of the threshold on BOTH sides of it, for each border — and the cost of every
+    pixel must be bit-identical across the three gather forms, both kernels, and equal to the oracle's restatement of the fast
+    arithmetic (S7), which always clamps."""
+    imgs, K, R, t = _scene_rotated()
+    ms = {}
+    for name, (bg, mix) in (("buffer", (True, True)), ("global", (False, True)), ("bytes", (True, False))):
+        m = _matcher(0, bg, mix_gather=mix)
+        m.set_views(imgs, K, R, t)
+        ms[name] = m
+    near = np.zeros((4, 2), np.int64)             # per border: pixels just inside / just outside the decision's threshold
+    scored = 0
+    normals = [(0.0, 0.0, -1.0), (0.35, -0.2, -1.0), (-0.5, 0.3, -1.0)]
+    depths = [40.0, 9.0, 4.0, 2.2, 1.45, 1.1, 0.83, 0.61, 0.47, 0.36, 0.3]
+    for view in (1, 2, 3):
+        orc = ol.Oracle(imgs, K, R, t, 1e-3, 1e6, box=11, n_best=1, seed=3, subset=[view], flags=ol.FLAGS_FAST_8BIT_IMAGERY)
+        orc.set_rcp_table(ol.rcp_table_from_device(ms["buffer"]))
+        for nv in normals:
+            n = np.array(nv, np.float64)
+            n /= np.linalg.norm(n)
+            for z0 in depths:
+                planes = np.zeros((H, W, 4), np.float32)
+                planes[..., :3] = n.astype(np.float32)
+                planes[..., 3] = np.float32(-n[2] * z0)             # the plane through (0, 0, z0) on the optical axis
+                c_ref = orc.pm_cost_planes(planes)[0]
+                got = {}
+                for name, m in ms.items():
+                    m.set_view_subset([view])
+                    got[name + "_full"] = m.pm_cost_planes(planes)[0]
+                    got[name + "_sweep"] = _sweep_cost(m, planes)
+                for k, v in got.items():
+                    assert np.array_equal(v, c_ref), (view, nv, z0, k, int((v != c_ref).sum()))
+                scored += int((c_ref < 2.0).sum())
+                for b, mg in enumerate(_centre_extent_margins(orc.homography(view, planes[0, 0]))):
+                    near[b, 0] += int(((mg >= 0) & (mg < 0.25)).sum())
+                    near[b, 1] += int(((mg < 0) & (mg > -0.25)).sum())
+        assert not orc.rcp_out_of_range
+    assert scored > 100000
+    assert (near > 0).all(), near               # every border's threshold approached from both sides
+    for m in ms.values():
+        m.close()

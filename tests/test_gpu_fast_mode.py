@@ -97,7 +97,11 @@ def _normal_error_deg(normal, gt_normal_world):
     return torch.rad2deg(2.0 * torch.asin((chord / 2.0).clamp(max=1.0)))
 
 
-def _better_than_control(agree, control):
+def _better_than_control(agree, control, floors):
+    """the control-relative bar, plus conservative ABSOLUTE floors per configuration (round-4 advice: a control that happens to be
+    loose for a scene or seed must not let a several-fold regression through): `floors` = (depth_within_1e-3, depth_within_1e-2),
+    the floors of rounds 2-3, each a stated margin below what is measured"""
+    assert agree["depth_within_1e-3"] >= floors[0] and agree["depth_within_1e-2"] >= floors[1], (floors, agree["depth_within_1e-3"], agree["depth_within_1e-2"])
     for k in ("identical_depth", "depth_within_1e-4", "depth_within_1e-3", "depth_within_1e-2", "angle_within_0.1deg", "angle_within_1deg"):
         assert agree[k] >= control[k] - 0.002, (k, agree[k], control[k])
     for k in ("depth_within_1e-3", "depth_within_1e-2"):      # disagreement <= half the reseeded control's
@@ -131,7 +135,7 @@ def test_cfg1_fast_run_vs_oracle():
         agree[f"mean_cost_{tag}"] = mc
     agree["control_oracle_vs_oracle_reseeded"] = control
     _record("cfg1_fast_vs_oracle_640x480_4views_8iters", agree)
-    _better_than_control(agree, control)
+    _better_than_control(agree, control, floors=(0.88, 0.995))            # measured 0.900 / 0.9977
     assert agree["valid_mismatch"] < 1e-3, agree
     # the same solution, statistically
     assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_oracle"]) < 1e-3, agree
@@ -167,7 +171,7 @@ def test_cfg2_fast_run_vs_strict_full_size():
         agree[f"mean_cost_{tag}"] = mc
     agree["control_strict_vs_strict_reseeded"] = control
     _record("cfg2_fast_vs_strict_6048x4032_10views_8iters", agree)
-    _better_than_control(agree, control)
+    _better_than_control(agree, control, floors=(0.99, 0.999))            # measured 0.9981 / 0.99997
     assert agree["valid_mismatch"] < 1e-3, agree
     assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_strict"]) < 5e-4, agree
     assert abs(agree["mean_cost_fast"] - agree["mean_cost_strict"]) < 2e-5, agree
@@ -201,7 +205,7 @@ def test_other_windows_fast_run_vs_strict(box, n_best):
         agree[f"mean_cost_{tag}"] = mc
     agree["control_strict_vs_strict_reseeded"] = control
     _record(f"box{box}_nbest{n_best}_fast_vs_strict_{w}x{h}_{n}views_6iters", agree)
-    _better_than_control(agree, control)
+    _better_than_control(agree, control, floors=(0.98, 0.9995))           # measured 0.9900-0.9993 / >= 0.9997
     # f = 1129 px here: a 1e-3 depth change is 0.011 px of disparity (between cfg1's 0.004 and cfg2's 0.034)
     assert agree["valid_mismatch"] < 1e-3, agree
     assert abs(agree["gt_1pct_fast"] - agree["gt_1pct_strict"]) < 2e-3, agree
@@ -256,7 +260,7 @@ def test_diverged_pixels_are_valid_patchmatch_steps(mid_scene, colour):
     assert (worse > COST_P99).mean() < 0.01 if div.any() else True, rec      # ... and beyond its p99 in under 1 % of the diverged pixels
     assert np.percentile(gap, 50) <= COST_P99 if div.any() else True, rec    # the two outcomes are near-ties by the oracle's own score
     assert (cost[swept] <= start_c[swept]).all()             # greedy in the GPU's own arithmetic: strictly never up
-    assert same[swept].mean() > 0.5, rec                     # recorded, not fitted (85-86 % measured): the checks above carry the statement
+    assert same[swept].mean() >= 0.75, rec                   # 85-86 % measured; the checks above carry the statement, this floor catches a several-fold regression
 
 
 def test_cost_of_a_given_plane_percentiles(small_scene, mid_scene):

@@ -600,6 +600,44 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     m.close()
 
 
+def test_wmf_infinite_values_at_reliable_taps_sort_like_the_reference(small_scene):
+    """an infinite normal component inside a reliable window: the 64-bit (value, slot) sort key classifies infinities before the
+    slot bits go into the mantissa (they would make a signalling NaN, which v_min_f64 quiets instead of replacing, and the
+    network would lose a slot): -inf first, +inf last, ties in tap order, like the reference's `>` bubble sort (gipuma.cu:1560-1616)"""
+    sc = small_scene
+    h, w = sc.h, sc.w
+    orc, m = _prepared_pair(sc, 8)
+    rng = np.random.default_rng(5)
+    planes = orc.norm4.copy()
+    r = rng.uniform(size=(h, w))
+    planes[..., 0][r < 0.03] = np.inf
+    planes[..., 0][(r >= 0.03) & (r < 0.06)] = -np.inf
+    planes[..., 2][(r >= 0.06) & (r < 0.08)] = np.inf
+    planes[..., 1][(r >= 0.08) & (r < 0.09)] = -np.inf
+    orc.norm4[:] = planes                         # lines->depth stays as getview left it: the depth list is finite
+    m.set_plane(planes, orc.c.copy())
+    scale = (rng.uniform(size=(h, w)) < 0.8).astype(np.float32)
+    orc.scale[:] = scale
+    m.set_reliable_mask(scale)
+    labels = np.zeros((h, w), np.int32)
+    text = np.array([1.0], np.float32)
+    orc.set_regions(labels, text)
+    m.set_regions(labels, text)
+    for it in range(4):
+        orc.wmf_detect(it)
+    m.wmf(4, False)
+    got = m.get_reliable_mask()
+    assert np.array_equal(got, orc.scale)
+    assert 0.02 < (got != scale).mean() < 0.98
+    for it in range(2):
+        orc.wmf_fill(it)
+    m.wmf(2, True)
+    got_planes = m.get_plane()[0]
+    same = (got_planes.view(np.uint32) == orc.norm4.view(np.uint32)) | (np.isnan(got_planes) & np.isnan(orc.norm4))
+    assert same.all(), int((~same).sum())
+    m.close()
+
+
 @pytest.mark.parametrize("knob,value", [("TSAR_RANSAC_CHAIN", "8"), ("TSAR_RANSAC_CHAIN", "4"), ("TSAR_RANSAC_CHAIN", "16"),
                                         ("TSAR_RANSAC_WGS", "1"), ("TSAR_RANSAC_WGS", "2"), ("TSAR_RANSAC_WGS", "4"), ("TSAR_RANSAC_WGS", "7"),
                                         ("TSAR_RANSAC_LOOKAHEAD", "1"), ("TSAR_RANSAC_LOOKAHEAD", "2"), ("TSAR_RANSAC_LOOKAHEAD", "3"),

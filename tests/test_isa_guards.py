@@ -74,3 +74,33 @@ def test_no_instruction_touches_a_gather_in_flight(tmp_path, unit):
         if int(mv.group(1)) <= 4:                    # (the 32-entry best-N selection of long lists is allowed its extra registers)
             assert vgpr <= 128, f"{name}: {vgpr} VGPRs (four waves per SIMD need <= 128)"
     assert seen >= 4
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_wmf_kernels_keep_their_keys_in_registers(tmp_path):
+    """wmf_detect / wmf_fill hold 122 fp64 sort keys in 244 VGPRs, the rest in AGPRs, at one wave per SIMD
+    (__launch_bounds__(64, 1), wmf_kernels.hip).  If a compiler or flag change moved those keys to scratch the result would stay
+    bit-exact and the kernels would be several times slower — the failure this file exists for.  Recorded budget (round 5):
+    333 / 334 registers (256 VGPRs + 77 / 78 AGPRs), 0 spills, 48 bytes of scratch per lane (the tap descriptor handed by
+    reference to the one non-inlined sort function), 39 040 bytes of LDS, 2 802 v_min_f64 / v_max_f64 (the network exists ONCE)."""
+    import re
+    out = tmp_path / "wmf.s"
+    subprocess.run([os.path.join(ROOT, "tools", "isa.sh"), os.path.join(ROOT, "tsar-mvs_amd", "csrc", "wmf_kernels.hip"), str(out)], check=True, capture_output=True, timeout=900)
+    txt = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+        name, body = m.group(1), m.group(2)
+        if "wmf_detect_kernel" not in name and "wmf_fill_kernel" not in name:
+            continue
+        seen += 1
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        assert scratch <= 64, f"{name}: {scratch} bytes of scratch per lane (recorded 48): sort keys or weights went to scratch"
+        assert 244 <= vgpr <= 512, f"{name}: {vgpr} registers"
+        assert lds <= 40 * 1024, f"{name}: {lds} bytes of LDS (four workgroups per CU need <= 40 KiB)"
+    assert seen == 2
+    spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", txt)]
+    assert spills and max(spills) == 0, spills
+    n_ce = len(re.findall(r"v_min_f64|v_max_f64", txt))
+    assert 2802 <= n_ce <= 2802 + 2 * 122 + 16, f"{n_ce} f64 min / max instructions: the sorting network must exist once in the binary"

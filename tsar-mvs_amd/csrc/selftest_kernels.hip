@@ -62,12 +62,19 @@ __global__ __launch_bounds__(ST_BLOCK) void divide_random_kernel(uint32_t per_th
 
 // sqrt_rsq_exact against sqrtf.  mode 0: EVERY mantissa in the binades [1, 2) and [2, 4) — both exponent parities, 2^24 inputs: the
 // rounding of Markstein's correction depends on the mantissa and the parity only while every intermediate stays normal; mode 1:
-// 2^24 random inputs with exponents across the guard range [2^-100, 2^100] (the scaling argument, sampled).
+// 2^24 random inputs with exponents across the guard range [2^-100, 2^100] (the scaling argument, sampled); mode 3: 2^24 random
+// mantissas spread evenly over the 67 binades the production operands can fall into (what the per-context probe adds to mode 0).
 __global__ __launch_bounds__(ST_BLOCK) void sqrt_enumerate_kernel(int mode, uint32_t seed_lo, uint32_t seed_hi, unsigned long long* out) {
     const uint32_t i = blockIdx.x * ST_BLOCK + threadIdx.x;            // 2^24 threads
     float x;
     if (mode == 0 || mode == 2) x = __uint_as_float(0x3f800000u + i);   // 1.0 .. 4.0 - ulp
-    else {
+    else if (mode == 3) {
+        // the PRODUCTION operand range: var_ref * var_src with both variances in [1e-5, 255^2], i.e. [1e-10, 4.3e9] — exponents
+        // 2^-34 .. 2^32 (67 binades), every one of them with 2^24 / 67 random mantissas
+        const Rand4 rn = philox_uniform4(i, 0u, 0x5a18u, seed_lo, seed_hi);
+        const uint32_t m = (uint32_t)(rn.u[0] * 16777216.0f) - 1u, e = 93u + i % 67u;
+        x = __uint_as_float((e << 23) | (m & 0x7fffffu));
+    } else {
         const Rand4 rn = philox_uniform4(i, 0u, 0x5a17u, seed_lo, seed_hi);
         const uint32_t m = (uint32_t)(rn.u[0] * 16777216.0f) - 1u, e = 27u + (uint32_t)(rn.u[1] * 200.0f) % 200u;   // 2^-100 .. 2^99
         x = __uint_as_float((e << 23) | (m & 0x7fffffu));

@@ -372,23 +372,22 @@ static int probe_exact_divide(tsar_ctx* ctx) {
 }
 // The same for the square root of the cost's tail (sqrt_rsq_exact, tsar_device_math.h), which BOTH arithmetic modes run on 8-bit
 // imagery: all 2^24 mantissa / exponent-parity cases against sqrtf on the device, once per context (~0.2 ms).
+// Second pass (round 5): the enumeration covers two binades; that the result carries to other exponents rests on v_rsq_f32 scaling
+// exactly with the exponent, so 2^24 random mantissas spread over the 67 binades the tail's operands can reach (var_ref * var_src in
+// [1e-10, 4.3e9]) are checked per context as well.  Run only for contexts whose views are 8-bit imagery: the float-imagery loop and
+// the refinement operators keep sqrtf.
 static int probe_exact_sqrt(tsar_ctx* ctx) {
     if (ctx->exact_sqrt_probe != 0) return ctx->exact_sqrt_probe;
-    uint64_t bad = 0;
+    uint64_t bad = 0, bad_range = 0;
     if (tsar_selftest_sqrt(ctx, 0, 0, &bad) != TSAR_OK) return 0;
-    ctx->exact_sqrt_probe = bad == 0 ? 1 : -1;
+    if (tsar_selftest_sqrt(ctx, 3, 0x5EED5A17ull, &bad_range) != TSAR_OK) return 0;
+    ctx->exact_sqrt_probe = (bad | bad_range) == 0 ? 1 : -1;
     return ctx->exact_sqrt_probe;
 }
 
 extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
     CHECK_CTX(ctx);
     if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
-    {
-        const int ps = probe_exact_sqrt(ctx);
-        if (ps == 0) return TSAR_ERR_HIP;
-        if (ps < 0) return fail(ctx, TSAR_ERR_HIP, "this device's v_rsq_f32 does not give correctly rounded square roots through the one-correction sequence of the cost's tail "
-                                                   "(tsar_selftest_sqrt found mismatches against sqrtf): refused rather than run with costs that differ from the oracle's");
-    }
     if (ctx->params.flags & TSAR_FLAG_STRICT_DIV) {
         const int pr = probe_exact_divide(ctx);
         if (pr == 0) return TSAR_ERR_HIP;
@@ -432,6 +431,12 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     TSAR_HIP_TRY(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     TSAR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     sc.use_quad = hflag ? 0 : 1;
+    if (sc.use_quad) {   // the 8-bit tap loops are the only users of sqrt_rsq_exact: probed for the contexts that will run them
+        const int ps = probe_exact_sqrt(ctx);
+        if (ps == 0) return TSAR_ERR_HIP;
+        if (ps < 0) return fail(ctx, TSAR_ERR_HIP, "this device's v_rsq_f32 does not give correctly rounded square roots through the one-correction sequence of the cost's tail "
+                                                   "(tsar_selftest_sqrt found mismatches against sqrtf): refused rather than run with costs that differ from the oracle's");
+    }
     for (int v = 0; v < n_views; v++) { sc.view[v].img = ctx->img[v]; sc.view[v].quad = ctx->quad[v]; sc.view[v].dquad = nullptr; }
     if (!sc.use_quad)
         for (auto& q : ctx->quad) dev_free(q);              // (float imagery: the textures are not used; re-allocated if a later call needs them)
@@ -956,7 +961,7 @@ extern "C" int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint
 }
 extern "C" int tsar_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, uint64_t* mismatches_out) {
     CHECK_CTX(ctx);
-    if (mode < 0 || mode > 2 || !mismatches_out) return fail(ctx, TSAR_ERR_INVALID, "mode in 0..2");
+    if (mode < 0 || mode > 3 || !mismatches_out) return fail(ctx, TSAR_ERR_INVALID, "mode in 0..3");
     ScratchScope scratch(ctx);
     unsigned long long* dc = (unsigned long long*)scratch.alloc(sizeof(unsigned long long));
     if (!dc) { scratch.release(); return fail(ctx, TSAR_ERR_NOMEM, "device allocation failed"); }

@@ -48,7 +48,8 @@ struct WmfLds {
 // negative value 127 - slot, since a larger mantissa is then the smaller number.  Two different floats differ by at least 2^29
 // double-ulps, so the slot bits only ever break ties, in tap order.  +0 with slot bits is a subnormal double (fp64 subnormals are not
 // flushed in this mode): zeros order by slot and stay between the negatives and the positives.  Invalid slots get huge keys
-// (2^1023 + slot) and sort last; a NaN value becomes 2^1022 + slot (v_min_f64 returns the other operand), so the keys are always a
+// (2^1023 + slot) and sort last; a NaN value becomes 2^1022 + slot (v_min_f64 returns the other operand) and an infinity +-2^1000 with
+// its slot bits (classified BEFORE the slot bits go in: they would turn it into a signalling NaN), so the keys are always a
 // permutation.  A compare-exchange is two instructions, the network (wmf_sort_network.h: Batcher's odd-even merge sort, 1401
 // comparators) 2 802 per list against ~30 000 for the counting; the 122 keys live in 244 VGPRs (the rest spills to AGPRs), so the
 // kernel runs ONE wave per SIMD — with a ninth of the instructions to issue, and with everything a lone wave would wait for kept
@@ -58,6 +59,10 @@ DEVFN double wmf_key(float v, int k, uint32_t valid_mask) {       // valid_mask:
     const double d = (double)(v + 0.0f);                          // + 0.0f: -0 -> +0
     uint32_t lo = (uint32_t)__double_as_longlong(d), hi = (uint32_t)((unsigned long long)__double_as_longlong(d) >> 32);
     const uint32_t m = (uint32_t)((int32_t)hi >> 31);             // all ones for a negative value
+    // +-inf: slot bits in an infinity's mantissa would make a signalling NaN, which v_min_f64 quiets instead of replacing (IEEE mode)
+    // and the network would then lose a slot.  An infinity becomes +-2^1000 instead — beyond every finite float, below the NaN and
+    // invalid-slot keys — so that -inf sorts first and +inf last among the values, ties in tap order, like the reference's `>` sort.
+    hi -= ((hi & 0x7FFFFFFFu) == 0x7FF00000u && lo == 0u) ? 0x01800000u : 0u;      // 0x7FF.. -> 0x7E7..
     lo |= (uint32_t)k ^ (m & 127u);
     double key = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     const double nan_key = __longlong_as_double((long long)((0x7FD00000ull << 32) | (unsigned)k));
