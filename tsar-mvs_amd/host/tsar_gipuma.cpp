@@ -16,6 +16,10 @@
 //   --all --fuse       after matching, every view's depth / normal map is gathered from the GPU that produced it to GPU 0
 //                      over xGMI (tsar_peer_copy) and fused there (tsar_fuse) into D/APD/APD_TSAR.ply — the fuser of
 //                      x/1.sh:30 without the round trip through .dmb files (which are still written)
+//   --all resumes: a view whose APD/<id>/TSAR_disp.dmb and TSAR_normals.dmb are complete (the reference's header, main.cpp:1817-1860 /
+//                      fileIoUtils.h:333-381, and exactly h*w*nb floats behind it) is skipped — the output files are the per-view
+//                      checkpoints; --force recomputes.  A view that fails on one GPU is retried once on the next
+//                      GPU's worker with a fresh context; the exit status is non-zero if any view's outputs are still missing.
 //   --num_consistent= --reproj_error= --depth_diff= --angle= --used_list=   the fuser's options (x/1.sh:20-30), for --fuse
 //   --seed=S, --strict, --fix-quirks, --texture-filter-8bit (TSAR_FLAG_TEX_FILTER_8BIT)
 // Images: binary PGM (the image has no JPEG decoder; `python -m tsar_mvs_amd.io convert a.jpg a.pgm`).
@@ -48,7 +52,7 @@ struct Options {
     std::string images_folder, mslp_folder, krt_file, output_folder;
     int iterations = 8, blocksize = 19, n_best = 2, cost_comb = TSAR_COMB_BEST_N;   // algorithmparameters.h:21-52
     float cam_scale = 1.0f, depth_min = -1.f, depth_max = -1.f;
-    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false, tex8 = false, timing = false;
+    bool all = false, strict = false, fix_quirks = false, color = false, display_outputs = false, fuse = false, tex8 = false, timing = false, force = false;
     tsar_fusion_params fusion{};
     int gpus = 1, workers = 1;      // --all: worker threads per GPU; each overlaps its file output with the next view's kernels
     uint64_t seed = 0;
@@ -111,7 +115,7 @@ static void usage() {
     printf("usage: tsar_gipuma <ref image> <source images...> -images_folder DIR/ -mslp_folder DIR/ [-krt_file F] [-output_folder DIR]\n"
            "                   [--iterations=N] [--blocksize=N] [--cost_comb=all|best_n|angle|good] [--n_best=N] [--cam_scale=S]\n"
            "                   [--depth_min=D --depth_max=D] [--mode=patchmatch|load|tsar] [--all --gpus=N --workers=W] [--seed=S] [--strict] [--fix-quirks] [--texture-filter-8bit] [-color_processing] [--display_outputs] [--timing]\n"
-           "       tsar_gipuma --all [--gpus=N] [--fuse [--num_consistent=N --reproj_error=PX --depth_diff=REL --angle=DEG --used_list=0|1]]\n"
+           "       tsar_gipuma --all [--gpus=N] [--force] [--fuse [--num_consistent=N --reproj_error=PX --depth_diff=REL --angle=DEG --used_list=0|1]]\n"
            "                   -images_folder DIR/ -mslp_folder DIR/ [options]\n");
 }
 
@@ -152,6 +156,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
         }
         else if (!strcmp(a, "--all")) o.all = true;
         else if (!strcmp(a, "--fuse")) o.fuse = true;
+        else if (!strcmp(a, "--force")) o.force = true;                        // --all: recompute views whose outputs are already there
         else if (starts("--num_consistent=")) o.fusion.num_consistent = atoi(a + 17);
         else if (starts("--reproj_error=")) o.fusion.reproj_error = (float)atof(a + 15);
         else if (starts("--depth_diff=")) o.fusion.depth_diff = (float)atof(a + 13);
@@ -277,6 +282,28 @@ static bool write_view_files(const HostResult& r) {   // the two files side by s
     return normals.get() && depth_ok;
 }
 
+// Fault injection for the re-queue path (tests): TSAR_GIPUMA_INJECT_FAILURE=<view id>[:<times>] makes the first <times> (default 1)
+// attempts at that view fail after its context exists, the way a device-side error would (the context is dropped).
+#include <atomic>
+static int g_inject_view = -1;
+static std::atomic<int> g_inject_left{0};
+static void read_injection() {
+    const char* e = getenv("TSAR_GIPUMA_INJECT_FAILURE");
+    if (!e || !*e) return;
+    g_inject_view = atoi(e);
+    const char* c = strchr(e, ':');
+    g_inject_left = c ? atoi(c + 1) : 1;
+}
+static std::string view_dir_of(const Options& o, int ref) { char b[32]; snprintf(b, sizeof b, "%08d", ref); return o.mslp_folder + "APD/" + b + "/"; }
+static std::string view_image_of(const Options& o, int ref) { char b[32]; snprintf(b, sizeof b, "%08d.pgm", ref); return o.images_folder + pnm_name(b, o.color ? ".ppm" : ".pgm"); }
+// the done marker of a view: both output maps complete for the size of its reference image
+static bool outputs_complete(const Options& o, int ref) {
+    int w = 0, h = 0;
+    if (!pnm_size(view_image_of(o, ref), w, h)) return false;
+    const std::string d = view_dir_of(o, ref);
+    return dmb_complete(d + "TSAR_disp.dmb", h, w, 1) && dmb_complete(d + "TSAR_normals.dmb", h, w, 3);
+}
+
 static int run_view(const Options& o, int device, const std::vector<std::string>& names, const std::vector<int>& subset_slots, int ref_id, double* seconds,
                     DeviceResult* keep = nullptr, HostResult* reuse = nullptr, bool defer_write = false, ExternalInputs* preloaded = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -354,6 +381,11 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     p.flags = (o.strict ? TSAR_FLAG_STRICT_DIV : 0) | (o.fix_quirks ? (TSAR_FLAG_FIX_DOWN_FAR_SEED | TSAR_FLAG_FIX_RIGHT_FAR_CMP) : 0) |
               (o.tex8 ? TSAR_FLAG_TEX_FILTER_8BIT : 0);
     if (tsar_set_params(ctx, &p) != TSAR_OK) return fail("tsar_set_params");
+    if (ref_id == g_inject_view && g_inject_left.fetch_sub(1) > 0) {
+        fprintf(stderr, "view %08d on gpu %d: injected failure (TSAR_GIPUMA_INJECT_FAILURE)\n", ref_id, device);
+        drop_ctx();
+        return -1;
+    }
     if (o.timing) { tsar_enable_kernel_timing(ctx, 1); tsar_reset_kernel_timing(ctx); }
     stamp(external ? "context + reference image (external maps and weak.png still loading)" : "context + images + cameras (concurrent)");
     const bool resident = (int)dev_ptrs.size() == n;
@@ -454,6 +486,7 @@ int main(int argc, char** argv) {
     if (o.images_folder.back() != '/') o.images_folder += '/';
     std::map<int, std::vector<int>> pairs;
     const bool have_pairs = read_pairs(o.mslp_folder + "pair.txt", pairs);
+    read_injection();
     if (o.all) {
         if (!have_pairs) { fprintf(stderr, "--all needs %spair.txt\n", o.mslp_folder.c_str()); return 1; }
         std::vector<int> refs;
@@ -462,6 +495,25 @@ int main(int argc, char** argv) {
         const int nthr = ngpu * (o.workers < 1 ? 1 : o.workers);   // worker t drives GPU t % ngpu with its own context
         std::vector<int> status(nthr, 0);
         std::vector<DeviceResult> kept(o.fuse ? refs.size() : 0);
+        // resume: the views whose output files are complete are not matched again (decided up front, so that nothing is read ahead for them)
+        std::vector<char> skip(refs.size(), 0);
+        std::vector<int> view_rc(refs.size(), 0), view_gpu(refs.size(), -1);
+        size_t n_skip = 0;
+        if (!o.force)
+            for (size_t k = 0; k < refs.size(); k++) n_skip += (skip[k] = outputs_complete(o, refs[k]) ? 1 : 0);
+        if (n_skip) printf("resuming: %zu of %zu views already have complete TSAR_disp.dmb / TSAR_normals.dmb and are skipped (--force recomputes them)\n", n_skip, refs.size());
+        // --fuse needs a skipped view's maps on a device all the same: read back from its files
+        auto load_kept = [&](size_t k, int g) {
+            std::vector<float> d, nr;
+            int h = 0, w = 0, nb = 0, h2 = 0, w2 = 0, nb2 = 0;
+            const std::string dir = view_dir_of(o, refs[k]);
+            if (!read_dmb(dir + "TSAR_disp.dmb", d, h, w, nb) || !read_dmb(dir + "TSAR_normals.dmb", nr, h2, w2, nb2) || h != h2 || w != w2 || nb != 1 || nb2 != 3) return false;
+            DeviceResult& r = kept[k];
+            r.device = g; r.w = w; r.h = h;
+            r.depth = (float*)tsar_device_alloc(g, d.size() * 4);
+            r.normal = (float*)tsar_device_alloc(g, nr.size() * 4);
+            return r.depth && r.normal && tsar_device_write(g, r.depth, d.data(), d.size() * 4) == TSAR_OK && tsar_device_write(g, r.normal, nr.data(), nr.size() * 4) == TSAR_OK;
+        };
         std::vector<std::thread> th;
         for (int t = 0; t < nthr; t++)
             th.emplace_back([&, t]() {
@@ -481,11 +533,17 @@ int main(int argc, char** argv) {
                 const size_t RING = std::max<size_t>(2, std::min<size_t>(8, 16 / (size_t)nthr));
                 std::vector<ExternalInputs> inputs(RING);
                 for (auto& in : inputs) in.pinned = true;
-                auto view_dir = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d", ref); return o.mslp_folder + "APD/" + b + "/"; };
-                auto ref_image = [&](int ref) { char b[32]; snprintf(b, sizeof b, "%08d.pgm", ref); return o.images_folder + pnm_name(b, o.color ? ".ppm" : ".pgm"); };
+                auto view_dir = [&](int ref) { return view_dir_of(o, ref); };
+                auto ref_image = [&](int ref) { return view_image_of(o, ref); };
                 size_t turn = 0;
                 for (size_t k = t; k < refs.size(); k += nthr, turn++) {   // round-robin: every view of a scene costs the same
                     const int ref = refs[k];
+                    view_gpu[k] = g;
+                    if (skip[k]) {
+                        printf("view %08d: outputs present, skipped\n", ref);
+                        if (o.fuse && !load_kept(k, g)) { fprintf(stderr, "view %08d: cannot read its output files back for --fuse\n", ref); view_rc[k] = -1; }
+                        continue;
+                    }
                     char buf[32];
                     std::vector<std::string> names;
                     snprintf(buf, sizeof buf, "%08d.pgm", ref);
@@ -499,22 +557,46 @@ int main(int argc, char** argv) {
                         for (size_t j = 1; j < RING; j++) {
                             ExternalInputs& ahead = inputs[(turn + j) % RING];
                             const size_t kk = k + j * nthr;
-                            if (kk < refs.size() && !ahead.started) ahead.start(view_dir(refs[kk]), o.mode == "tsar", ref_image(refs[kk]));
+                            if (kk < refs.size() && !skip[kk] && !ahead.started) ahead.start(view_dir(refs[kk]), o.mode == "tsar", ref_image(refs[kk]));
                         }
                     }
                     const int rc = run_view(o, g, names, {}, ref, &sec, o.fuse ? &kept[k] : nullptr, &hr, /*defer_write*/ true, external ? &inputs[turn % RING] : nullptr);
                     printf("view %08d on gpu %d: %s (%.2f s)\n", ref, g, rc == 0 ? "ok" : "FAILED", sec);
-                    if (rc != 0) status[t] = rc;   // a failed view does not stop the others
-                    else writing[turn & 1] = std::async(std::launch::async, [&hr]() { return write_view_files(hr); });
+                    view_rc[k] = rc;               // a failed view does not stop the others; it is retried below
+                    if (rc == 0) writing[turn & 1] = std::async(std::launch::async, [&hr]() { return write_view_files(hr); });
                 }
                 for (auto& f : writing)
                     if (f.valid() && !f.get()) status[t] = -1;
                 tsar_destroy(worker_ctx);
             });
         for (auto& t : th) t.join();
+        // re-queue: a view that failed is tried once more on the NEXT gpu's turn (the same one when there is only one) with a
+        // context of its own, created fresh and destroyed with the view — never the worker context the failure left behind
+        for (size_t k = 0; k < refs.size(); k++) {
+            if (view_rc[k] == 0 || skip[k]) continue;
+            const int g2 = (view_gpu[k] + 1) % ngpu;
+            printf("view %08d FAILED on gpu %d: retrying once on gpu %d with a fresh context\n", refs[k], view_gpu[k], g2);
+            if (o.fuse) {
+                if (kept[k].depth) tsar_device_free(kept[k].device, kept[k].depth);
+                if (kept[k].normal) tsar_device_free(kept[k].device, kept[k].normal);
+                kept[k] = DeviceResult{};
+            }
+            char buf[32];
+            std::vector<std::string> names;
+            snprintf(buf, sizeof buf, "%08d.pgm", refs[k]);
+            names.push_back(buf);
+            for (int sv : pairs[refs[k]]) { snprintf(buf, sizeof buf, "%08d.pgm", sv); names.push_back(buf); }
+            double sec = 0;
+            view_rc[k] = run_view(o, g2, names, {}, refs[k], &sec, o.fuse ? &kept[k] : nullptr);
+            printf("view %08d on gpu %d (retry): %s (%.2f s)\n", refs[k], g2, view_rc[k] == 0 ? "ok" : "FAILED", sec);
+        }
         g_device_images.release();
+        int missing = 0;
+        for (size_t k = 0; k < refs.size(); k++)
+            if (view_rc[k] != 0 || !outputs_complete(o, refs[k])) { fprintf(stderr, "view %08d: outputs missing or incomplete\n", refs[k]); missing++; }
         for (int s : status)
-            if (s != 0) return 1;
+            if (s != 0) missing++;      // a file of an otherwise matched view could not be written
+        if (missing) return 1;
         if (o.fuse) {
             // gather: every view's maps to GPU 0 (peer copies over xGMI; views matched on GPU 0 are already there), then fuse
             const auto t0 = std::chrono::steady_clock::now();

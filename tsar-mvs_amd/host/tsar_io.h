@@ -82,6 +82,27 @@ static inline bool read_pgm(const std::string& path, FloatVec& img, int& w, int&
 // Binary PPM (P6), one channel extracted.  -color_processing in the reference uploads float4 (B, G, R, alpha) textures
 // but the matching cost fetches them with tex2D<float> (gipuma.cu:247,262,265), i.e. it matches on the first channel of
 // OpenCV's BGR order: blue.  channel: 0 = R, 1 = G, 2 = B of the PPM.
+// size of a binary PGM / PPM from its header alone (a resumed --all run checks finished views without decoding anything)
+static inline bool pnm_size(const std::string& path, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int got = 0, vals[2] = {0, 0};
+    bool ok = fscanf(f, "%2s", magic) == 1 && (strcmp(magic, "P5") == 0 || strcmp(magic, "P6") == 0);
+    while (ok && got < 2) {
+        int c = fgetc(f);
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (c == EOF) { ok = false; break; }
+        if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+        ungetc(c, f);
+        if (fscanf(f, "%d", &vals[got]) != 1) { ok = false; break; }
+        got++;
+    }
+    fclose(f);
+    w = vals[0]; h = vals[1];
+    return ok && w > 0 && h > 0;
+}
+
 template <class FloatVec>
 static inline bool read_ppm_channel(const std::string& path, int channel, FloatVec& img, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -119,6 +140,18 @@ static inline bool write_dmb(const std::string& path, const float* data, int h, 
     fclose(f);
     return ok;
 }
+// a .dmb that is all there: the reference's header (type 1, h, w, nb: fileIoUtils.h:333-381) and exactly h * w * nb floats behind it —
+// the done marker of a view (the per-view output files are the coarse checkpoints)
+static inline bool dmb_complete(const std::string& path, int h, int w, int nb) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    int32_t hd[4] = {0, 0, 0, 0};
+    bool ok = fread(hd, 4, 4, f) == 4 && hd[0] == 1 && hd[1] == h && hd[2] == w && hd[3] == nb;
+    if (ok) ok = fseek(f, 0, SEEK_END) == 0 && ftell(f) == (long)(16 + (size_t)h * w * nb * 4);
+    fclose(f);
+    return ok;
+}
+
 template <class FloatVector>   // std::vector<float> with any allocator
 static inline bool read_dmb(const std::string& path, FloatVector& data, int& h, int& w, int& nb) {
     FILE* f = fopen(path.c_str(), "rb");
