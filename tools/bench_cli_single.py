@@ -45,7 +45,7 @@ def main():
             ok = out.returncode == 0
             print(f"run {r}: {dt:.2f} s for one {args.width}x{args.height} view with {args.views - 1} sources = {args.width * args.height / dt / 1e6:.1f} Mpix/s "
                   f"process-to-files, {'ok' if ok else 'FAILED'}", flush=True)
-            print("   " + " | ".join(l for l in out.stdout.strip().splitlines()[-6:]), flush=True)
+            print("   " + "\n   ".join(l for l in out.stdout.strip().splitlines()[-6:]), flush=True)
             if not ok:
                 print(out.stderr[-2000:])
                 sys.exit(1)

@@ -75,7 +75,8 @@ struct PinnedAllocator {
     static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }
     static std::map<void*, bool>& pinned() { static std::map<void*, bool>* s = new std::map<void*, bool>; return *s; }
     T* allocate(size_t n) {
-        void* p = tsar_host_alloc(n * sizeof(T));
+        static const bool no_pin = getenv("TSAR_GIPUMA_NO_PIN") != nullptr;      // diagnostics: plain pageable result buffers
+        void* p = no_pin ? nullptr : tsar_host_alloc(n * sizeof(T));
         const bool is_pinned = p != nullptr;
         if (!p) p = malloc(n * sizeof(T));
         if (!p) throw std::bad_alloc();
@@ -328,7 +329,13 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     tsar_ctx** shared = reuse ? reuse->shared_ctx : nullptr;
     tsar_ctx* ctx = shared ? *shared : nullptr;
     std::future<int> creating;
-    if (!ctx) creating = std::async(std::launch::async, [&ctx, device]() { return tsar_create(device, &ctx); });
+    double ms_create = 0.0, ms_decode = 0.0;                        // --timing: the two concurrent legs of the start-up, each on its own clock
+    if (!ctx) creating = std::async(std::launch::async, [&ctx, device, &ms_create]() {
+        const auto c0 = std::chrono::steady_clock::now();
+        const int rc = tsar_create(device, &ctx);
+        ms_create = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+        return rc;
+    });
     ExternalInputs own_inputs;
     ExternalInputs& ext = (preloaded && preloaded->started && preloaded->dir == out_dir) ? *preloaded : own_inputs;   // --all: started a view ago
     if (external && !ext.started) ext.start(out_dir, tsar_mode, "");
@@ -339,6 +346,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         for (int i = 0; i < n; i++)
             decoding.push_back(std::async(std::launch::async, [&o, &names, i]() { return g_images.get(o.images_folder + pnm_name(names[i], o.color ? ".ppm" : ".pgm")); }));
         for (int i = 0; i < n; i++) gray[i] = decoding[i].get();
+        ms_decode = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     // (the map / mask readers are joined where their data is needed — set_views and load_planes run while weak.png is still
     // inflating — or by `consumed` on an early return)
@@ -388,6 +396,11 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     }
     if (o.timing) { tsar_enable_kernel_timing(ctx, 1); tsar_reset_kernel_timing(ctx); }
     stamp(external ? "context + reference image (external maps and weak.png still loading)" : "context + images + cameras (concurrent)");
+    if (o.timing) {
+        char buf[96];
+        snprintf(buf, sizeof buf, " [tsar_create %.1f beside decode of %d images %.1f]", ms_create, n, ms_decode);
+        steps += buf;
+    }
     const bool resident = (int)dev_ptrs.size() == n;
     if (tsar_set_views(ctx, n, w, h, resident ? dev_ptrs.data() : ptrs.data(), resident ? TSAR_MEM_DEVICE : TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
     if (!subset_slots.empty() && !external) {
@@ -395,6 +408,10 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         if (tsar_set_view_subset(ctx, (int)s.size(), s.data()) != TSAR_OK) return fail("tsar_set_view_subset");
     }
     stamp("set_views");
+    // (One view per process: releasing the decoded images — 1.07 GB of host memory at ETH3D size — here, on a helper thread beside the
+    // kernels, instead of leaving them to the exit path was measured and removed: the caller waits ~40 ms per GB the process still
+    // holds when main() leaves, but the munmap contends with the runtime's own mappings while pm_init's code object loads, 65 -> 200 ms
+    // for that step, and the invocation got slower, 1239 -> 1323 ms median: profiles/r05/cli_single_view_breakdown.txt.)
     mkdirs(out_dir);
     const size_t np = (size_t)w * h;
     // page-locking the result buffers of a one-view process (0.39 GB at ETH3D size, ~0.1 s) happens beside the kernels
@@ -411,8 +428,9 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         stamp("load_planes");
     } else {
         if (tsar_pm_init(ctx) != TSAR_OK) return fail("tsar_pm_init");
+        if (o.timing) { tsar_synchronize(ctx); stamp("pm_init (first launch of its code object)"); }
         if (tsar_pm_iterate(ctx, o.iterations) != TSAR_OK) return fail("tsar_pm_iterate");
-        stamp("pm_init + pm_iterate");
+        stamp(o.timing ? "pm_iterate" : "pm_init + pm_iterate");
     }
     if (tsar_mode) {
         // the reference's live path, runGipuma main.cpp:1493-1783: external planes (above: firstcuda) -> reliability mask
@@ -476,7 +494,29 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     return 0;
 }
 
+// --timing, one view per process: milliseconds from exec() to now, from the process's start time in /proc (10 ms resolution)
+static double ms_since_exec() {
+    FILE* f = fopen("/proc/self/stat", "r");
+    if (!f) return -1.0;
+    char buf[2048];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    const char* p = strrchr(buf, ')');                 // the command name may contain blanks
+    if (!p) return -1.0;
+    unsigned long long start_ticks = 0;
+    int field = 2;
+    for (p++; *p && field < 22; p++)
+        if (*p == ' ') { field++; if (field == 22) start_ticks = strtoull(p + 1, nullptr, 10); }
+    double up = 0.0;
+    f = fopen("/proc/uptime", "r");
+    if (!f || fscanf(f, "%lf", &up) != 1) { if (f) fclose(f); return -1.0; }
+    fclose(f);
+    return (up - (double)start_ticks / (double)sysconf(_SC_CLK_TCK)) * 1e3;
+}
+
 int main(int argc, char** argv) {
+    const double ms_exec_to_main = ms_since_exec();
     Options o;
     tsar_default_fusion_params(&o.fusion);
     const int pr = parse_args(argc, argv, o);
@@ -683,6 +723,8 @@ int main(int argc, char** argv) {
     single.shared_ctx = &single_ctx;
     const int rc = run_view(o, 0, o.images, slots, camera_id, &sec, nullptr, &single);
     printf("Total runtime including disk i/o: %gsec\n", sec);
+    if (o.timing) printf("process (ms since exec, 10 ms resolution): main entered at %.0f, leaving at %.0f (what the caller waits for beyond that is the teardown of the process's GPU state by the driver)\n",
+                         ms_exec_to_main, ms_since_exec());
     fflush(nullptr);
     _exit(rc == 0 ? 0 : 1);
 }
