@@ -177,6 +177,12 @@ int tsar_set_params(tsar_ctx* ctx, const tsar_params* p);
  * then return TSAR_ERR_STATE. */
 int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem,
                    const tsar_camera* cams);
+/* The same with the 8-bit decode itself: gray[i] points at w*h bytes, widened to float on the device — bit for bit what
+ * tsar_set_views does with (float)gray[i][p], which is how the reference fills its textures (imread(..., GRAYSCALE) ->
+ * convertTo(CV_32F), main.cpp:1302,1423).  A quarter of the bytes cross PCIe and the caller holds no float copies of its images
+ * (1.07 GB at ETH3D size with ten sources): what tsar_gipuma hands over. */
+int tsar_set_views_u8(tsar_ctx* ctx, int n_views, int w, int h, const uint8_t* const* gray, int mem,
+                      const tsar_camera* cams);
 /* indices (1..n_views-1) of the source views used for matching, in pair.txt order; at most 32 (the reference's
  * costVector[32], gipuma.cu:467).  Default after tsar_set_views: the first min(n_views - 1, 32) source views.
  * Changing the subset invalidates the stored costs' meaning: the next sweep re-scores neighbours it would otherwise skip. */

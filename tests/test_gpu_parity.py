@@ -897,3 +897,44 @@ def test_end_to_end_match_then_fuse():
     n1 = np.array([0.55, 0.10, -1.0]); n1 /= np.linalg.norm(n1)
     dist = np.minimum(np.minimum(np.abs(X @ n0 + 1.6), np.abs(X @ n1 - 0.15)), np.abs(np.linalg.norm(X - np.array([-0.9, 0.35, -0.2]), axis=1) - 0.75))
     assert np.percentile(dist, 90) < 0.05
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_set_views_u8_is_set_views_on_the_widened_bytes(small_scene, strict):
+    """tsar_set_views_u8 (the 8-bit decode itself, widened on the device — what tsar_gipuma hands over) against tsar_set_views on
+    (float)bytes: the same planes, costs and output maps bit for bit, from host bytes and from device-resident bytes; an image
+    whose size is not a multiple of 16 takes the kernel's scalar tail"""
+    import torch
+    sc = small_scene
+    flags = api.FLAG_STRICT_DIV if strict else 0
+    outs = []
+    for form in ("float", "u8 host", "u8 device"):
+        m = api.Matcher()
+        m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=sc.depth_min, depth_max=sc.depth_max, seed=9, flags=flags))
+        if form == "float":
+            m.set_views(sc.images, sc.K, sc.R, sc.t)
+        elif form == "u8 host":
+            m.set_views([im.numpy().astype(np.uint8) for im in sc.images], sc.K, sc.R, sc.t, u8=True)
+        else:
+            m.set_views([im.to(torch.uint8).cuda().contiguous() for im in sc.images], sc.K, sc.R, sc.t, u8=True)
+        m.pm_init()
+        m.pm_iterate(2)
+        planes, cost, bv, ratio = m.get_plane()
+        m.compute_disp()
+        outs.append((planes.view(np.uint32).copy(), cost.copy(), bv.copy(), m.get_result(("depth",))["depth"].copy()))
+        m.close()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+    # odd size (93 x 61 = 5673 pixels, not a multiple of 16) and the refinement operators' reference-only form
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(61, 93)).astype(np.uint8)
+    res = []
+    for u8 in (False, True):
+        m = api.Matcher()
+        m.set_params(api.default_params(box_hsize=11, box_vsize=11, n_best=1, depth_min=1.0, depth_max=10.0))
+        m.set_views([img if u8 else img.astype(np.float32)], sc.K[:1], sc.R[:1], sc.t[:1], u8=u8)
+        labels, text, size = m.detect_weak_texture()
+        res.append((labels.copy(), text.copy()))
+        m.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

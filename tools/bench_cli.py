@@ -39,7 +39,7 @@ def main():
         tio.export_scene(sc, root)
         for wk in args.workers:
             t0 = time.perf_counter()
-            out = subprocess.run([cli, "--all", "--gpus=1", f"--workers={wk}", "-mslp_folder", root, "-images_folder", root + "images/",
+            out = subprocess.run([cli, "--all", "--force", "--gpus=1", f"--workers={wk}", "-mslp_folder", root, "-images_folder", root + "images/",
                                   f"--iterations={args.iters}", "--blocksize=11", "--n_best=1", *(["--fuse"] if args.fuse else []), *(["--timing"] if args.timing else [])], capture_output=True, text=True)
             dt = time.perf_counter() - t0
             ok = out.returncode == 0 and all(os.path.exists(root + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(args.views))

@@ -60,7 +60,7 @@ def main():
             tio.write_reliable_mask(apd + "weak.png", good)
         names = [f"{k:08d}.pgm" for k in range(args.views)]
         common = ["-mslp_folder", root, "-images_folder", root + "images/", "--blocksize=11", "--n_best=1", "--mode=tsar", *(["--timing"] if args.timing else [])]
-        cmd = [cli, "--all", "--gpus=1", f"--workers={args.workers}", *common] if args.all else [cli, *names, *common]
+        cmd = [cli, "--all", "--force", "--gpus=1", f"--workers={args.workers}", *common] if args.all else [cli, *names, *common]
         n_done = args.views if args.all else 1
         for r in range(args.repeat):
             t0 = time.perf_counter()

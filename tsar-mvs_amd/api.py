@@ -63,7 +63,7 @@ SPIXEL_DTYPE = np.dtype([("center", np.float32, 2), ("color", np.float32, 4), ("
 # every symbol include/tsar.h declares (tests check that the library exports exactly these)
 ABI_SYMBOLS = [
     "tsar_create", "tsar_destroy", "tsar_last_error", "tsar_version", "tsar_get_stream", "tsar_synchronize",
-    "tsar_default_params", "tsar_set_params", "tsar_set_views", "tsar_set_view_subset",
+    "tsar_default_params", "tsar_set_params", "tsar_set_views", "tsar_set_views_u8", "tsar_set_view_subset",
     "tsar_pm_init", "tsar_pm_iterate", "tsar_pm_iterate_final", "tsar_pm_sweep", "tsar_set_sweep_counter", "tsar_pm_cost_planes", "tsar_set_plane", "tsar_get_plane",
     "tsar_load_planes", "tsar_compute_disp", "tsar_compute_disp_final", "tsar_depth_to_plane", "tsar_get_result",
     "tsar_set_reliable_mask", "tsar_get_reliable_mask", "tsar_lrdiff", "tsar_getview", "tsar_wmf", "tsar_set_regions", "tsar_detect_weak_texture", "tsar_ransac_regions",
@@ -96,6 +96,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_default_slic_settings.argtypes = [C.POINTER(SlicSettings)]
     L.tsar_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
     L.tsar_set_views.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(Camera)]
+    L.tsar_set_views_u8.argtypes = L.tsar_set_views.argtypes
     L.tsar_set_view_subset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.tsar_pm_init.argtypes = [C.c_void_p]
     L.tsar_pm_iterate.argtypes = [C.c_void_p, C.c_int]
@@ -211,9 +212,10 @@ class Matcher:
         self._chk(self.L.tsar_set_params(self._ctx, C.byref(params)))
         self.params = params
 
-    def set_views(self, images, K, R, t):
+    def set_views(self, images, K, R, t, u8: bool = False):
         """images: list of [h, w] float32 arrays/tensors (view 0 = reference); K, R, t: per-view
-        intrinsics and world->camera extrinsics as in cams/%08d_cam.txt."""
+        intrinsics and world->camera extrinsics as in cams/%08d_cam.txt.  u8: the images are uint8 (the 8-bit decode itself)
+        and go through tsar_set_views_u8, which widens them on the device."""
         n = len(images)
         first = images[0]
         h, w = int(first.shape[0]), int(first.shape[1])
@@ -222,8 +224,10 @@ class Matcher:
         for i, im in enumerate(images):
             assert tuple(im.shape) == (h, w)
             if not _is_torch(im):
-                im = np.ascontiguousarray(im, dtype=np.float32)
+                im = np.ascontiguousarray(im, dtype=np.uint8 if u8 else np.float32)
                 self._keep.append(im)
+            elif u8:
+                assert str(im.dtype) == "torch.uint8" and im.is_contiguous()
             p, kind = _ptr(im)
             ptrs[i] = p
             kinds.add(kind)
@@ -236,7 +240,7 @@ class Matcher:
             cams[i].K[:] = K[i].tolist()
             cams[i].R[:] = R[i].tolist()
             cams[i].t[:] = t[i].tolist()
-        self._chk(self.L.tsar_set_views(self._ctx, n, w, h, ptrs, kinds.pop(), cams))
+        self._chk((self.L.tsar_set_views_u8 if u8 else self.L.tsar_set_views)(self._ctx, n, w, h, ptrs, kinds.pop(), cams))
         self._keep.clear()
         self.w, self.h, self.n_views = w, h, n
 

@@ -39,6 +39,30 @@ int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, in
     return TSAR_OK;
 }
 
+// tsar_set_views_u8: the 8-bit decode widened on the device (what the reference does on the host, convertTo(CV_32F), main.cpp:1423):
+// a quarter of the bytes cross PCIe and the caller never holds 4-byte copies of its images.  16 pixels per thread.
+__global__ __launch_bounds__(EW_BLOCK) void expand_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * EW_BLOCK + threadIdx.x) * 16;
+    if (i + 16 <= n && (((uintptr_t)(in + i)) & 15) == 0) {
+        const uint4 v = *(const uint4*)(in + i);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            *(float4*)(out + i + 4 * k) = make_float4((float)(wds[k] & 0xffu), (float)((wds[k] >> 8) & 0xffu), (float)((wds[k] >> 16) & 0xffu), (float)(wds[k] >> 24));
+    } else {
+        for (size_t k = i; k < n && k < i + 16; k++) out[k] = (float)in[k];
+    }
+}
+int launch_expand_u8(tsar_ctx* ctx, const uint8_t* in, float* out, size_t n) {
+    const size_t threads = (n + 15) / 16;
+    {
+        ScopedKernelTimer tm(ctx, "expand_u8");
+        hipLaunchKernelGGL(expand_u8_kernel, dim3((unsigned)((threads + EW_BLOCK - 1) / EW_BLOCK)), dim3(EW_BLOCK), 0, ctx->stream, in, out, n);
+    }
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
 // The same quads as four halfs per entry, (t00, d1 = t10 - t00, d2 = t01 - t00, d3 = t11 - t10 - t01 + t00): what the fast
 // arithmetic's blend (t00 + ax d1) + ay (d2 + ax d3) consumes (oracle S7 (6)).  All four are integers of magnitude <= 510, exact in
 // fp16, so three v_fma_mix_f32 read them straight out of the gathered 8 bytes — no byte converts, no subtractions (pm_tap_r5.h MIX).

@@ -385,7 +385,8 @@ static int probe_exact_sqrt(tsar_ctx* ctx) {
     return ctx->exact_sqrt_probe;
 }
 
-extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
+// tsar_set_views (elem = 4: float32 images) and tsar_set_views_u8 (elem = 1: the 8-bit decode itself, widened on the device)
+static int set_views_impl(tsar_ctx* ctx, int n_views, int w, int h, const void* const* gray, int elem, int mem, const tsar_camera* cams) {
     CHECK_CTX(ctx);
     if (!ctx->have_params) return fail(ctx, TSAR_ERR_STATE, "tsar_set_params must be called before tsar_set_views");
     if (ctx->params.flags & TSAR_FLAG_STRICT_DIV) {
@@ -424,7 +425,17 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     for (int v = 0; v < n_views; v++) {
         if (!ctx->img[v]) TRY(dev_alloc(ctx, &ctx->img[v], np));
         if (!ctx->quad[v]) TRY(dev_alloc(ctx, &ctx->quad[v], (size_t)(w + 2) * (h + 2)));
-        TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->img[v], gray[v], np * sizeof(float), in_kind(mem), ctx->stream));
+        if (elem == 4) {
+            TSAR_HIP_TRY(ctx, hipMemcpyAsync(ctx->img[v], gray[v], np * sizeof(float), in_kind(mem), ctx->stream));
+        } else if (mem == TSAR_MEM_DEVICE) {
+            TRY(launch_expand_u8(ctx, (const uint8_t*)gray[v], ctx->img[v], np));
+        } else {
+            // host bytes: staged in the view's own quad-texture buffer ((w + 2)(h + 2) dwords, written only by build_quad below, which
+            // reads img[v]) — no extra allocation, and the copies of the views follow each other on the stream without a sync
+            uint8_t* stage = (uint8_t*)ctx->quad[v];
+            TSAR_HIP_TRY(ctx, hipMemcpyAsync(stage, gray[v], np, hipMemcpyHostToDevice, ctx->stream));
+            TRY(launch_expand_u8(ctx, stage, ctx->img[v], np));
+        }
         TRY(launch_build_quad(ctx, ctx->img[v], ctx->quad[v], w, h, dflag));
     }
     int hflag = 0;
@@ -490,6 +501,13 @@ extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const fl
     TRY(upload_scene(ctx));
     ctx->have_views = true;
     return TSAR_OK;
+}
+
+extern "C" int tsar_set_views(tsar_ctx* ctx, int n_views, int w, int h, const float* const* gray, int mem, const tsar_camera* cams) {
+    return set_views_impl(ctx, n_views, w, h, (const void* const*)gray, 4, mem, cams);
+}
+extern "C" int tsar_set_views_u8(tsar_ctx* ctx, int n_views, int w, int h, const uint8_t* const* gray, int mem, const tsar_camera* cams) {
+    return set_views_impl(ctx, n_views, w, h, (const void* const*)gray, 1, mem, cams);
 }
 
 extern "C" int tsar_set_view_subset(tsar_ctx* ctx, int n, const int32_t* view_idx) {

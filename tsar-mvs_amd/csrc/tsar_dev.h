@@ -203,6 +203,7 @@ struct ScopedKernelTimer {
 
 // ---- launchers implemented in the .hip files -----------------------------------------------------
 int launch_build_quad(tsar_ctx* ctx, const float* img, uint32_t* quad, int w, int h, int* nonintegral_flag);
+int launch_expand_u8(tsar_ctx* ctx, const uint8_t* in, float* out, size_t n);   // plane_kernels.hip
 int launch_build_dquad(tsar_ctx* ctx, const uint32_t* quad, uint2* dquad, int w, int h);
 int launch_pm_init(tsar_ctx* ctx);
 bool probe_d16_hi_zeroes(tsar_ctx* ctx);   // pm_sweep.hip

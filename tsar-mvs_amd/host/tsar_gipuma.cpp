@@ -63,9 +63,10 @@ struct Options {
 
 // The result buffers (depth / normal maps out) are page-locked (tsar_host_alloc): the DMA engine then writes them directly
 // instead of going through the runtime's bounce buffers (a 6048 x 4032 view's results: 9 ms instead of 30), and one set serves
-// every view of a worker.  Decoded images are NOT page-locked: each is uploaded once per GPU (DeviceImageCache), and
-// page-locking 97 MB costs ~25 ms — serialised inside the runtime — against the ~7 ms it would take off that one copy.
+// every view of a worker.  Decoded images stay BYTES on the host (round 5: tsar_set_views_u8 widens them on the device) and are
+// not page-locked: each is uploaded once per GPU (DeviceImageCache).
 // Falls back to ordinary memory when page-locking fails.
+static bool g_pin_results = false;     // set by main() for --all
 template <class T>
 struct PinnedAllocator {
     typedef T value_type;
@@ -75,8 +76,12 @@ struct PinnedAllocator {
     static std::mutex& mu() { static std::mutex* m = new std::mutex; return *m; }
     static std::map<void*, bool>& pinned() { static std::map<void*, bool>* s = new std::map<void*, bool>; return *s; }
     T* allocate(size_t n) {
-        static const bool no_pin = getenv("TSAR_GIPUMA_NO_PIN") != nullptr;      // diagnostics: plain pageable result buffers
-        void* p = no_pin ? nullptr : tsar_host_alloc(n * sizeof(T));
+        // page-locked only where a buffer is reused (--all: one set per worker for every view).  One view per process: page-locking
+        // 0.39 GB on a helper thread beside the kernels contends with the runtime while pm_init's code object loads (that step
+        // 13 -> 81 ms) to save 5 ms of copy: pageable there (profiles/r05/cli_single_view_breakdown.txt).  TSAR_GIPUMA_PIN=0/1 overrides.
+        static const char* knob = getenv("TSAR_GIPUMA_PIN");
+        const bool pin = knob ? knob[0] != '0' : g_pin_results;
+        void* p = pin ? tsar_host_alloc(n * sizeof(T)) : nullptr;
         const bool is_pinned = p != nullptr;
         if (!p) p = malloc(n * sizeof(T));
         if (!p) throw std::bad_alloc();
@@ -184,7 +189,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
 
 // Decoded images shared by all views of a run (--all visits every image as a reference once and as a source ~N times).
 struct ImageCache {
-    struct Entry { std::vector<float> gray; int w = 0, h = 0; bool ok = false; };
+    struct Entry { std::vector<uint8_t> gray; int w = 0, h = 0; bool ok = false; };      // the 8-bit decode as it is: widened to float on the device (tsar_set_views_u8)
     std::mutex mu;
     std::map<std::string, std::shared_ptr<Entry>> items;
     std::shared_ptr<Entry> get(const std::string& path) {
@@ -195,7 +200,7 @@ struct ImageCache {
         }
         auto e = std::make_shared<Entry>();                       // decode outside the lock; a rare double decode is harmless
         const bool ppm = path.size() > 4 && path.compare(path.size() - 4, 4, ".ppm") == 0;
-        e->ok = ppm ? read_ppm_channel(path, 2, e->gray, e->w, e->h) : read_pgm(path, e->gray, e->w, e->h);   // colour: blue, see tsar_io.h
+        e->ok = ppm ? read_ppm_channel(path, 2, e->gray, e->w, e->h) : read_pgm_u8(path, e->gray, e->w, e->h);   // colour: blue, see tsar_io.h
         std::lock_guard<std::mutex> lk(mu);
         auto ins = items.emplace(path, e);
         return ins.first->second;
@@ -208,13 +213,13 @@ static ImageCache g_images;
 // again (a scene's images are each the reference once and a source ~N times).
 struct DeviceImageCache {
     std::mutex mu;
-    std::map<std::pair<int, std::string>, float*> items;        // (device, path) -> device copy
-    const float* get(int device, const std::string& path, const ImageCache::Entry& host) {
+    std::map<std::pair<int, std::string>, uint8_t*> items;      // (device, path) -> device copy (bytes)
+    const uint8_t* get(int device, const std::string& path, const ImageCache::Entry& host) {
         std::lock_guard<std::mutex> lk(mu);                       // uploads are rare (once per image and device): serialised
         auto it = items.find({device, path});
         if (it != items.end()) return it->second;
-        const size_t bytes = (size_t)host.w * host.h * sizeof(float);
-        float* d = (float*)tsar_device_alloc(device, bytes);
+        const size_t bytes = (size_t)host.w * host.h;
+        uint8_t* d = (uint8_t*)tsar_device_alloc(device, bytes);
         if (!d) return nullptr;
         if (tsar_device_write(device, d, host.gray.data(), bytes) != TSAR_OK) { tsar_device_free(device, d); return nullptr; }
         items[{device, path}] = d;
@@ -356,7 +361,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     // a context is destroyed here only when this call owns it, or after a failure (the next view then starts from a fresh one)
     auto drop_ctx = [&]() { tsar_destroy(ctx); if (shared) *shared = nullptr; };
     auto fail = [&](const char* what) { fprintf(stderr, "%s: %s\n", what, tsar_last_error(ctx)); drop_ctx(); return -1; };
-    std::vector<const float*> ptrs(n), dev_ptrs;
+    std::vector<const uint8_t*> ptrs(n), dev_ptrs;
     std::vector<tsar_camera> cams(n);
     int w = 0, h = 0;
     float dmin = o.depth_min, dmax = o.depth_max;
@@ -368,7 +373,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); drop_ctx(); return -1; }
         ptrs[i] = gray[i]->gray.data();
         if (reuse && reuse->device_image_cache) {                 // --all: resident device copy (falls back to the host buffer)
-            const float* d = g_device_images.get(device, ip, *gray[i]);
+            const uint8_t* d = g_device_images.get(device, ip, *gray[i]);
             if (d) dev_ptrs.push_back(d);
         }
         CamFile cf;
@@ -402,7 +407,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
         steps += buf;
     }
     const bool resident = (int)dev_ptrs.size() == n;
-    if (tsar_set_views(ctx, n, w, h, resident ? dev_ptrs.data() : ptrs.data(), resident ? TSAR_MEM_DEVICE : TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views");
+    if (tsar_set_views_u8(ctx, n, w, h, resident ? dev_ptrs.data() : ptrs.data(), resident ? TSAR_MEM_DEVICE : TSAR_MEM_HOST, cams.data()) != TSAR_OK) return fail("tsar_set_views_u8");
     if (!subset_slots.empty() && !external) {
         std::vector<int32_t> s(subset_slots.begin(), subset_slots.end());
         if (tsar_set_view_subset(ctx, (int)s.size(), s.data()) != TSAR_OK) return fail("tsar_set_view_subset");
@@ -414,7 +419,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     // for that step, and the invocation got slower, 1239 -> 1323 ms median: profiles/r05/cli_single_view_breakdown.txt.)
     mkdirs(out_dir);
     const size_t np = (size_t)w * h;
-    // page-locking the result buffers of a one-view process (0.39 GB at ETH3D size, ~0.1 s) happens beside the kernels
+    // sizing (and, in --all, page-locking once per worker) of the result buffers happens beside the kernels
     HostResult local;
     HostResult& hr = reuse ? *reuse : local;
     std::future<void> sizing;
@@ -485,7 +490,8 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
             vis[k] = (uint16_t)(v <= 0.f ? 0 : v >= 65535.f ? 65535 : (int)lrintf(v));
         }
         if (!write_png_rgb16(out_dir + "TSAR_normals.png", vis.data(), w, h)) return -1;
-        if (!write_view_ply(out_dir + "TSAR_model.ply", depth.data(), normal.data(), gray[0]->gray.data(), w, h, cams[0])) return -1;
+        const std::vector<float> ref_gray(gray[0]->gray.begin(), gray[0]->gray.end());
+        if (!write_view_ply(out_dir + "TSAR_model.ply", depth.data(), normal.data(), ref_gray.data(), w, h, cams[0])) return -1;
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (seconds) *seconds = sec;
@@ -528,6 +534,7 @@ int main(int argc, char** argv) {
     const bool have_pairs = read_pairs(o.mslp_folder + "pair.txt", pairs);
     read_injection();
     if (o.all) {
+        g_pin_results = true;
         if (!have_pairs) { fprintf(stderr, "--all needs %spair.txt\n", o.mslp_folder.c_str()); return 1; }
         std::vector<int> refs;
         for (auto& kv : pairs) refs.push_back(kv.first);
@@ -675,7 +682,8 @@ int main(int argc, char** argv) {
                 auto img = g_images.get(o.images_folder + pnm_name(buf, o.color ? ".ppm" : ".pgm"));
                 float* g0 = (float*)tsar_device_alloc(0, np * 4);
                 if (g0) owned.push_back(g0);
-                if (!img->ok || !g0 || tsar_device_write(0, g0, img->gray.data(), np * 4) != TSAR_OK) { fprintf(stderr, "--fuse: image of view %08d\n", refs[k]); release(); return 1; }
+                const std::vector<float> img_f(img->gray.begin(), img->gray.end());      // the fuser colours its points from float images
+                if (!img->ok || img_f.size() != np || !g0 || tsar_device_write(0, g0, img_f.data(), np * 4) != TSAR_OK) { fprintf(stderr, "--fuse: image of view %08d\n", refs[k]); release(); return 1; }
                 pd[k] = d; pn[k] = nr; pg[k] = g0;
                 char cname[32];
                 snprintf(cname, sizeof cname, "%08d", refs[k]);

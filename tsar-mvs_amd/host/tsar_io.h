@@ -82,6 +82,32 @@ static inline bool read_pgm(const std::string& path, FloatVec& img, int& w, int&
 // Binary PPM (P6), one channel extracted.  -color_processing in the reference uploads float4 (B, G, R, alpha) textures
 // but the matching cost fetches them with tex2D<float> (gipuma.cu:247,262,265), i.e. it matches on the first channel of
 // OpenCV's BGR order: blue.  channel: 0 = R, 1 = G, 2 = B of the PPM.
+// a binary PGM as it is on disk: w*h bytes, read straight into the vector (no float copy: the library widens on the device,
+// tsar_set_views_u8)
+static inline bool read_pgm_u8(const std::string& path, std::vector<uint8_t>& img, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int got = 0, vals[3];
+    if (fscanf(f, "%2s", magic) != 1 || strcmp(magic, "P5") != 0) { fclose(f); return false; }
+    while (got < 3) {
+        int c = fgetc(f);
+        if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+        if (c == EOF) { fclose(f); return false; }
+        if (c == ' ' || c == '\n' || c == '\r' || c == '\t') continue;
+        ungetc(c, f);
+        if (fscanf(f, "%d", &vals[got]) != 1) { fclose(f); return false; }
+        got++;
+    }
+    fgetc(f);   // single whitespace after maxval
+    w = vals[0]; h = vals[1];
+    if (vals[2] > 255 || w <= 0 || h <= 0) { fclose(f); return false; }
+    img.resize((size_t)w * h);
+    const bool ok = fread(img.data(), 1, img.size(), f) == img.size();
+    fclose(f);
+    return ok;
+}
+
 // size of a binary PGM / PPM from its header alone (a resumed --all run checks finished views without decoding anything)
 static inline bool pnm_size(const std::string& path, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
