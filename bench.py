@@ -137,9 +137,17 @@ def host_boundary(args, sc):
         m.pm_init()
         m.compute_disp()
         m.get_result(out=bufs["pinned"])
-    for leg, imgs in (("pinned", pinned), ("pageable", pageable)):
+    # third leg (round 5): the 8-bit decode itself handed over as bytes, tsar_set_views_u8 — what tsar_gipuma does: a quarter of
+    # the bytes cross PCIe and the caller holds no float copies (same results bit for bit: tests/test_gpu_parity.py)
+    pinned_u8 = []
+    for im in pageable:
+        a = api.pinned_empty(im.shape, np.uint8)
+        a[...] = im.astype(np.uint8)
+        pinned_u8.append(a)
+    bufs["u8_pinned"] = bufs["pinned"]
+    for leg, imgs in (("pinned", pinned), ("pageable", pageable), ("u8_pinned", pinned_u8)):
         t0 = time.perf_counter()
-        m.set_views(imgs, sc.K, sc.R, sc.t)
+        m.set_views(imgs, sc.K, sc.R, sc.t, u8=leg.startswith("u8"))
         t1 = time.perf_counter()
         m.pm_init()
         m.pm_iterate(args.iters)
@@ -150,8 +158,8 @@ def host_boundary(args, sc):
         out[leg] = {"value": w * h / (t3 - t0) / 1e6, "unit": "Mpix/s", "set_views_h2d_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3,
                     "get_result_d2h_ms": (t3 - t2) * 1e3}
     m.close()
-    return {"value": out["pinned"]["value"], "unit": "Mpix/s", "pinned": out["pinned"], "pageable": out["pageable"],
-            "note": "host buffers in (H2D + quad build), host buffers out (D2H); one view; value = page-locked caller buffers (tsar_host_alloc)"}
+    return {"value": out["pinned"]["value"], "unit": "Mpix/s", "pinned": out["pinned"], "pageable": out["pageable"], "u8_pinned": out["u8_pinned"],
+            "note": "host buffers in (H2D + quad build), host buffers out (D2H); one view; value = page-locked float32 caller buffers (tsar_host_alloc); u8_pinned = the 8-bit decode handed over as bytes (tsar_set_views_u8)"}
 
 
 def tolerance_fast_vs_strict(fast, strict):
