@@ -418,3 +418,28 @@ def test_cli_all_requeues_a_failed_view_once(tmp_path):
     fix = subprocess.run([CLI, *common], capture_output=True, text=True)
     assert fix.returncode == 0 and fix.stdout.count("outputs present, skipped") == 3
     assert open(root + "APD/00000001/TSAR_disp.dmb", "rb").read() == want[1]
+
+
+def test_cli_all_resume_decision_needs_no_gpu(tmp_path):
+    """the resume half of --all on the CPU: with every view's output files complete the tool skips them all and exits 0 without ever
+    creating a context (so it runs here, where there is no device); with one file truncated that view is attempted, cannot get a
+    device, is retried once, and the exit status says a view is missing"""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present: the failing half of this test would match the view instead")
+    sc = synth.make_scene(64, 48, 2, seed=2)
+    root = str(tmp_path) + "/"
+    tio.export_scene(sc, root)
+    for v in range(3):
+        os.makedirs(root + f"APD/{v:08d}", exist_ok=True)
+        tio.write_dmb(root + f"APD/{v:08d}/TSAR_disp.dmb", np.ones((48, 64), np.float32))
+        tio.write_dmb(root + f"APD/{v:08d}/TSAR_normals.dmb", np.zeros((48, 64, 3), np.float32))
+    cmd = [CLI, "--all", "--gpus=1", "-mslp_folder", root, "-images_folder", root + "images/", "--iterations=1", "--blocksize=11", "--n_best=1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("outputs present, skipped") == 3 and "resuming: 3 of 3" in out.stdout
+    raw = open(root + "APD/00000001/TSAR_normals.dmb", "rb").read()
+    open(root + "APD/00000001/TSAR_normals.dmb", "wb").write(raw[:-4])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert out.stdout.count("outputs present, skipped") == 2 and "retrying once" in out.stdout
+    assert "view 00000001: outputs missing or incomplete" in out.stderr
