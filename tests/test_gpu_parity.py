@@ -600,6 +600,32 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     m.close()
 
 
+def test_wmf_on_float_imagery_keeps_the_direct_weights(small_scene):
+    """the filter's bilateral weight comes from two tables on 8-bit imagery (spatial factor per tap slot, colour factor per integer
+    difference: wmf_kernels.hip WmfLds); images that are not an 8-bit decode take the direct form exp(-cd / 9): same oracle, bit for bit"""
+    import dataclasses
+    sc = dataclasses.replace(small_scene, images=[im + 0.25 for im in small_scene.images])
+    h, w = sc.h, sc.w
+    orc, m = _prepared_pair(sc, 8)
+    rng = np.random.default_rng(0)
+    scale = (rng.uniform(size=(h, w)) < 0.7).astype(np.float32)
+    orc.scale[:] = scale
+    m.set_reliable_mask(scale)
+    labels = np.zeros((h, w), np.int32)
+    text = np.array([1.0], np.float32)
+    orc.set_regions(labels, text)
+    m.set_regions(labels, text)
+    for it in range(4):
+        orc.wmf_detect(it)
+    m.wmf(4, False)
+    assert np.array_equal(m.get_reliable_mask(), orc.scale)
+    for it in range(2):
+        orc.wmf_fill(it)
+    m.wmf(2, True)
+    assert np.array_equal(m.get_plane()[0].view(np.uint32), orc.norm4.view(np.uint32))
+    m.close()
+
+
 def test_wmf_infinite_values_at_reliable_taps_sort_like_the_reference(small_scene):
     """an infinite normal component inside a reliable window: the 64-bit (value, slot) sort key classifies infinities before the
     slot bits go into the mantissa (they would make a signalling NaN, which v_min_f64 quiets instead of replacing, and the

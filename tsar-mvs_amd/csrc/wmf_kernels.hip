@@ -36,6 +36,12 @@ DEVFN int slot_pixel_safe(const WmfTaps& t, int k, int w, int h) {
 struct WmfLds {
     float w[WMF_SLOTS * WMF_BLOCK];             // bilateral weight of every tap slot, [slot][thread]
     unsigned char pos[WMF_SLOTS * WMF_BLOCK];   // the list's sorted order, [rank][thread]
+    // The weight exp(-sd / 4) exp(-cd / 9) (gipuma.cu:1537-1550) factorises: sd depends on the tap slot alone (the same for every
+    // pixel of a launch), and on 8-bit imagery cd = |I(tap) - I(centre)| is an integer 0..255.  Both factors are tabulated once per
+    // workgroup by the same expressions — the same bits — and a tap costs a table look-up and one multiply instead of a square root,
+    // a division and two exponentials (~50 of the ~55 instructions of a tap; round 5).  Float imagery keeps the direct form.
+    float spatial[WMF_SLOTS - 1];               // exp(-sd / 4) per tap slot
+    float colour[256];                          // exp(-cd / 9) for cd = 0..255
 };
 
 // ---- the stable order from a SORTING NETWORK on (value, slot) keys ---------------------------------------------------------------------
@@ -169,10 +175,24 @@ DEVFN int weighted_median_slot(const WmfLds& l, int num, float half) {
     walk_ranked<true>(l, num, half, &k);
     return k;
 }
+// the two weight tables of WmfLds, by ALL 64 lanes of the workgroup (= one wave): called before any lane leaves the kernel
+DEVFN void init_weight_tables(const DevScene* __restrict__ sc, int radius, int gap, float sdiv, WmfLds& l) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < WMF_SLOTS - 1; k += WMF_BLOCK) {
+        const int ii = k / 11, jj = k - 11 * ii, i = -radius + ii * gap, j = -radius + jj * gap;
+        const float sd = sqrtf((float)(i * i + j * j)) / sdiv;
+        l.spatial[k] = tsar_expf(-sd / 4.0f);
+    }
+    if (sc->use_quad)
+        for (int e = tid; e < 256; e += WMF_BLOCK) l.colour[e] = tsar_expf(-(float)e / 9.0f);
+    __syncthreads();                            // one wave per workgroup: an LDS fence (s_waitcnt lgkmcnt(0) + s_barrier)
+}
+
 DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict__ scale_in, int x, int y, int radius, int gap, float sdiv, WmfTaps& t, WmfLds& l) {
     const float* __restrict__ img = sc->view[0].img;
     const int w = sc->w, h = sc->h;
     const float cen = img[(size_t)y * w + x];
+    const bool tables = sc->use_quad != 0;      // wave-uniform: 8-bit imagery (init_weight_tables ran before any lane left)
     int num = 0;
     uint64_t lo = 0, hi = 0;
     // The grid is 11 x 11 in every launch (radius = 5 gap).  One column of 11 taps at a time: the 22 loads (reliability flag and
@@ -196,14 +216,14 @@ DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict_
         for (int jj = 0; jj < 11; jj++) {
             const int j = -radius + jj * gap, py = y + j, slot = 11 * ii + jj;
             const bool ok = okx && py >= 0 && py < h && sv[jj] == 1.0f;
-            float wt = 0.f;
-            if (ok) {
-                const float cd = fabsf(iv[jj] - cen);
-                const float sd = sqrtf((float)(i * i + j * j)) / sdiv;
-                wt = tsar_expf(-sd / 4.0f) * tsar_expf(-cd / 9.0f);   // sigma_spatial 2, sigma_color 3 (gipuma.cu:1537-1550)
-                num++;
-                if (slot < 64) lo |= 1ull << slot; else hi |= 1ull << (slot - 64);
-            }
+            // sigma_spatial 2, sigma_color 3 (gipuma.cu:1537-1550): wt = exp(-sd / 4) * exp(-cd / 9), from the tables on 8-bit imagery
+            // (computed for every lane, kept where the tap is valid: no divergent block per tap)
+            const float cd = fabsf(iv[jj] - cen);
+            const float ws = l.spatial[slot];
+            const float wc = tables ? l.colour[min((int)cd, 255)] : tsar_expf(-cd / 9.0f);
+            const float wt = ok ? ws * wc : 0.f;
+            num += ok ? 1 : 0;
+            if (slot < 64) lo |= (uint64_t)ok << slot; else hi |= (uint64_t)ok << (slot - 64);
             l.w[slot * WMF_BLOCK + threadIdx.x] = wt;
         }
     }
@@ -269,11 +289,12 @@ __global__ __launch_bounds__(WMF_BLOCK, 1) void wmf_detect_kernel(const DevScene
                                                                float* __restrict__ scale_out, int iter) {
     const int w = sc->w, h = sc->h;
     const int p = blockIdx.x * WMF_BLOCK + threadIdx.x;
-    if (p >= w * h) return;
-    const int y = p / w, x = p - y * w;
     const int po = 1 << iter, repo = 1 << (3 - iter);
     const int radius = 80 / po, gap = 16 / po, ths = 24 / po;
     __shared__ WmfLds lds;
+    init_weight_tables(sc, radius, gap, (float)repo, lds);
+    if (p >= w * h) return;
+    const int y = p / w, x = p - y * w;
     WmfTaps t;
     float4 nm;
     float s = 0.0f;
@@ -294,12 +315,14 @@ __global__ __launch_bounds__(WMF_BLOCK, 1) void wmf_fill_kernel(const DevScene* 
                                                              float4* __restrict__ n_out, int iter) {
     const int w = sc->w, h = sc->h;
     const int p = blockIdx.x * WMF_BLOCK + threadIdx.x;
-    if (p >= w * h) return;
-    if (!(region_text[canny[p]] == 1.0f && scale_in[p] == 0.0f)) return;
-    const int y = p / w, x = p - y * w;
+    const bool active = p < w * h && region_text[canny[p]] == 1.0f && scale_in[p] == 0.0f;
+    if (!__any(active)) return;                 // (most workgroups: nothing unreliable in a textured region)
     const int po = 1 << iter;
     const int radius = 5 * po, gap = po, ths = 32 / po;
     __shared__ WmfLds lds;
+    init_weight_tables(sc, radius, gap, (float)po, lds);
+    if (!active) return;
+    const int y = p / w, x = p - y * w;
     WmfTaps t;
     float4 nm;
     const int num = collect_taps(sc, scale_in, x, y, radius, gap, (float)po, t, lds);
