@@ -1,0 +1,157 @@
+"""A second, independent restatement of the matching cost — numpy, float64, vectorised, written from the reference's text
+(pmCost gipuma.cu:229-298, getHomography_cu :207-224, getCorrespondingPoint_cu :161-171, pmCostMultiview_cu :455-518, the camera
+re-origin of cameraGeometryUtils.h:270-302) without looking at oracle/tsar_oracle.c's code — against the C oracle on random planes.
+
+gipuma.cu cannot be built here, so nothing pins the oracle's PatchMatch rows to outputs of the reference.  What
+this file adds is a restatement that shares no code, no language, no precision and no loop structure with the oracle: a misreading of
+the text would have to be made twice, in two different shapes, to go unseen.  The two agree to the rounding of fp32 (the oracle
+accumulates 36 taps in fp32; the cancellation in E[x^2] - E[x]^2 amplifies that): |cost difference| p50 4e-6, p99 4e-5, max 1e-4 measured
+(the same size as the library's fast-vs-strict arithmetic difference), and the
+minimum-variance cut-off (cost = 2) is taken by the same pixels except where a variance sits within rounding of 1e-5."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from tsar_mvs_amd import synth
+
+
+def _reorigin(K, R, t):
+    """cameras relative to the reference one (ref = K[I|0]): R_v R_0^T, t_v - R_v R_0^T t_0  (cameraGeometryUtils.h:270-302)"""
+    R0, t0 = R[0].astype(np.float64), t[0].astype(np.float64)
+    out = []
+    for v in range(len(K)):
+        Rv = R[v].astype(np.float64) @ R0.T
+        out.append((K[v].astype(np.float64), Rv, t[v].astype(np.float64) - Rv @ t0))
+    return out
+
+
+def _bilinear_clamped(img, u, v):
+    """tex2D(img, u + 0.5, v + 0.5) with clamp addressing and exact linear weights (the oracle's S3): sample at continuous (u, v)"""
+    h, w = img.shape
+    u = np.clip(u, -1.0, w)             # beyond one texel outside, clamping changes nothing: every texel involved is the edge one
+    v = np.clip(v, -1.0, h)
+    u0, v0 = np.floor(u), np.floor(v)
+    a, b = u - u0, v - v0
+    x0, x1 = np.clip(u0, 0, w - 1).astype(int), np.clip(u0 + 1, 0, w - 1).astype(int)
+    y0, y1 = np.clip(v0, 0, h - 1).astype(int), np.clip(v0 + 1, 0, h - 1).astype(int)
+    top = img[y0, x0] * (1 - a) + img[y0, x1] * a
+    bot = img[y1, x0] * (1 - a) + img[y1, x1] * a
+    return top * (1 - b) + bot * b
+
+
+def cost_float64(images, cams, view, planes, radius):
+    """pmCost of every pixel's plane against one source view, float64.  planes [h][w][4] = (n, d), n . X + d = 0 in reference-camera
+    coordinates; taps at -radius, -radius + 2, ..., radius in both directions (WIN_INCREMENT 2)."""
+    ref = images[0].astype(np.float64)
+    src = images[view].astype(np.float64)
+    h, w = ref.shape
+    K0, _, _ = cams[0]
+    Kv, Rv, tv = cams[view]
+    n, d = planes[..., :3].astype(np.float64), planes[..., 3].astype(np.float64)
+    # H = K_v (R_v - t_v n^T / d) K_0^-1, per pixel
+    M = Rv[None, None] - tv[None, None, :, None] * n[:, :, None, :] / d[:, :, None, None]
+    H = Kv[None, None] @ M @ np.linalg.inv(K0)[None, None]
+    ys, xs = np.mgrid[0:h, 0:w]
+    cen = ref
+    offs = range(-radius, radius + 1, 2)
+    acc = {k: np.zeros((h, w)) for k in ("w", "r", "rr", "s", "ss", "rs")}
+    for i in offs:
+        for j in offs:
+            px, py = xs + i, ys + j
+            r = ref[np.clip(py, 0, h - 1), np.clip(px, 0, w - 1)]
+            X = H[..., 0, 0] * px + H[..., 0, 1] * py + H[..., 0, 2]
+            Y = H[..., 1, 0] * px + H[..., 1, 1] * py + H[..., 1, 2]
+            Z = H[..., 2, 0] * px + H[..., 2, 1] * py + H[..., 2, 2]
+            s = _bilinear_clamped(src, X / Z, Y / Z)
+            wt = np.exp(-np.sqrt(float(i * i + j * j)) / (2.0 * 5.0 * 5.0) - np.abs(r - cen) / (2.0 * 3.0 * 3.0))
+            acc["w"] += wt
+            acc["r"] += wt * r
+            acc["rr"] += wt * r * r
+            acc["s"] += wt * s
+            acc["ss"] += wt * s * s
+            acc["rs"] += wt * r * s
+    m = {k: acc[k] / acc["w"] for k in ("r", "rr", "s", "ss", "rs")}
+    var_r, var_s = m["rr"] - m["r"] ** 2, m["ss"] - m["s"] ** 2
+    with np.errstate(all="ignore"):
+        c = np.clip(1.0 - (m["rs"] - m["r"] * m["s"]) / np.sqrt(var_r * var_s), 0.0, 2.0)
+    low = (var_r < 1e-5) | (var_s < 1e-5)
+    return np.where(low, 2.0, c), np.minimum(var_r, var_s)
+
+
+def _random_planes(orc, sc, seed):
+    rng = np.random.default_rng(seed)
+    h, w = sc.h, sc.w
+    out = np.empty((h, w, 4), np.float32)
+    for y in range(h):
+        for x in range(w):
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            if nrm @ orc.view_vector(x, y) > 0:
+                nrm = -nrm
+            nrm = nrm.astype(np.float32)
+            out[y, x, :3] = nrm
+            out[y, x, 3] = orc.getD(nrm, x, y, rng.uniform(sc.depth_min, sc.depth_max))
+    return out
+
+
+@pytest.mark.parametrize("box", [11, 7])
+def test_cost_of_random_and_true_planes_against_the_float64_restatement(small_scene, box):
+    sc = small_scene
+    images = [im.numpy() for im in sc.images]
+    cams = _reorigin(sc.K, sc.R, sc.t)
+    base = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, box=box, n_best=1)
+    for tag, planes in (("true", synth.gt_planes(sc).numpy()), ("random", _random_planes(base, sc, 5))):
+        per_view, vmins = [], []
+        for view in (1, 2, 3):
+            orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, box=box, n_best=1, subset=[view])
+            c32 = orc.pm_cost_planes(planes)[0].astype(np.float64)
+            c64, vmin = cost_float64(images, cams, view, planes, box // 2)
+            # pixels whose smaller variance sits within fp32 rounding of the 1e-5 cut-off may fall on either side of it
+            sure = np.abs(vmin - 1e-5) > 1e-3 * np.maximum(vmin, 1e-5) + 5e-3
+            assert np.array_equal((c32 == 2.0)[sure], (c64 == 2.0)[sure]), (tag, view)
+            d = np.abs(c32 - c64)[sure]
+            # fp32 sums of 16-36 products of magnitude ~2e4 carry ~4e-3 of rounding into a variance; the cost divides by it
+            assert np.percentile(d, 50) <= 1e-5 and np.percentile(d, 99) <= 2e-4, (tag, view, np.percentile(d, [50, 99]))     # measured 4e-6 / 4e-5
+            assert (d <= 2e-2 / vmin[sure] + 1e-4).all(), (tag, view, d.max())
+            assert (c64[sure] < 2.0).mean() > 0.5                                   # the planes score real windows
+            per_view.append(c64)
+            vmins.append(vmin)
+        # pmCostMultiview_cu: the mean of the n_best smallest valid costs, the best view, the ratio of the two smallest
+        stack = np.stack(per_view, -1)
+        vmin_all = np.min(np.stack(vmins, -1), -1)
+        order = np.sort(stack, -1)
+        valid = (stack < 2.0).sum(-1)
+        for n_best in (1, 2, 3):
+            orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, box=box, n_best=n_best)
+            c32, bv, ratio = orc.pm_cost_planes(planes)
+            k = np.minimum(valid, n_best)
+            want = np.where(k > 0, np.cumsum(order, -1)[np.arange(sc.h)[:, None], np.arange(sc.w)[None], np.maximum(k, 1) - 1] / np.maximum(k, 1), 2.0)
+            gap = order[..., 1] - order[..., 0]
+            clear = (np.abs(stack - 2.0).min(-1) > 1e-3) | (stack == 2.0).all(-1)       # no view within rounding of the validity bound
+            d = np.abs(c32 - want)[clear]
+            assert (d <= 2e-2 / np.maximum(vmin_all[clear], 1e-5) + 2e-4).all(), (tag, n_best, d.max())
+            if n_best == 1:
+                decided = clear & (gap > 1e-3) & (valid > 0)
+                assert np.array_equal(bv[decided], (np.argmin(stack, -1) + 1)[decided]), tag
+                two = decided & (valid >= 2)
+                # ratio = smallest / second smallest cost (gipuma.cu:505): each cost carries up to ~1e-4 of fp32 rounding
+                assert (np.abs(ratio - order[..., 0] / order[..., 1])[two] <= (3e-4 / order[..., 1] + 1e-4)[two]).all()
+
+
+def test_homography_against_float64(small_scene):
+    sc = small_scene
+    cams = _reorigin(sc.K, sc.R, sc.t)
+    orc = ol.Oracle([im.numpy() for im in sc.images], sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max)
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        d = rng.uniform(1.0, 12.0)
+        n4 = np.array([*n, d], np.float32)
+        for view in (1, 2, 3):
+            K0, _, _ = cams[0]
+            Kv, Rv, tv = cams[view]
+            H64 = Kv @ (Rv - np.outer(tv, n4[:3].astype(np.float64)) / float(n4[3])) @ np.linalg.inv(K0)
+            H32 = orc.homography(view, n4).astype(np.float64)
+            # fp32 through two 3x3 products with intrinsics of magnitude ~50: a few 1e-6 (measured 4.5e-6)
+            assert np.max(np.abs(H32 - H64)) <= 2e-5 * np.max(np.abs(H64)) + 1e-5
