@@ -62,19 +62,29 @@ struct WmfLds {
 // sort last; a NaN value becomes 2^1022 + slot (v_min_f64 returns the other operand) and an infinity +-2^1000 with its slot bits
 // (classified BEFORE the slot bits go in: they would turn it into a signalling NaN), so the keys are always a permutation.  A
 // compare-exchange is two instructions and moves no payload.
-DEVFN double wmf_key(float v, int k, uint32_t valid_mask) {       // valid_mask: all ones / zero
+// Built in three steps, so that the non-finite cases cost nothing where there are none: (1) convert and put the slot bits in — pure bit
+// arithmetic, an infinity or NaN just carries them along; (2) ONLY IF some lane of the wave loaded a non-finite value in this batch
+// (a running maximum of the value bits tells): +-inf -> +-2^1000 (slot bits in an infinity's mantissa would make a signalling NaN,
+// which v_min_f64 quiets instead of ordering, and the network would lose a slot; so -inf sorts first and +inf last among the values,
+// ties in tap order, like the reference's `>` sort), NaN -> 2^1022 + slot; (3) the validity mask: an invalid slot is 2^1023 + slot.
+DEVFN double wmf_key_bits(float v, int k) {
     const double d = (double)(v + 0.0f);                          // + 0.0f: -0 -> +0
-    uint32_t lo = (uint32_t)__double_as_longlong(d), hi = (uint32_t)((unsigned long long)__double_as_longlong(d) >> 32);
+    uint32_t lo = (uint32_t)__double_as_longlong(d);
+    const uint32_t hi = (uint32_t)((unsigned long long)__double_as_longlong(d) >> 32);
     const uint32_t m = (uint32_t)((int32_t)hi >> 31);             // all ones for a negative value
-    // +-inf: slot bits in an infinity's mantissa would make a signalling NaN, which v_min_f64 quiets instead of replacing (IEEE mode)
-    // and the network would then lose a slot.  An infinity becomes +-2^1000 instead — beyond every finite float, below the NaN and
-    // invalid-slot keys — so that -inf sorts first and +inf last among the values, ties in tap order, like the reference's `>` sort.
-    hi -= ((hi & 0x7FFFFFFFu) == 0x7FF00000u && lo == 0u) ? 0x01800000u : 0u;      // 0x7FF.. -> 0x7E7..
     lo |= (uint32_t)k ^ (m & 127u);
-    double key = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-    const double nan_key = __longlong_as_double((long long)((0x7FD00000ull << 32) | (unsigned)k));
-    asm("v_min_f64 %0, %1, %2" : "=v"(key) : "v"(key), "v"(nan_key));                    // NaN -> its own large key
-    lo = (uint32_t)__double_as_longlong(key); hi = (uint32_t)((unsigned long long)__double_as_longlong(key) >> 32);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+DEVFN double wmf_key_fix_nonfinite(double key, int k) {
+    uint32_t lo = (uint32_t)__double_as_longlong(key), hi = (uint32_t)((unsigned long long)__double_as_longlong(key) >> 32);
+    if ((hi & 0x7FF00000u) == 0x7FF00000u) {
+        if ((hi & 0x000FFFFFu) == 0u && (lo >> 29) == 0u) hi -= 0x01800000u;      // +-inf (mantissa zero above the slot bits) -> +-2^1000
+        else { hi = 0x7FD00000u; lo = (uint32_t)k; }                             // NaN -> 2^1022 + k
+    }
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+DEVFN double wmf_key_mask(double key, int k, uint32_t valid_mask) {
+    uint32_t lo = (uint32_t)__double_as_longlong(key), hi = (uint32_t)((unsigned long long)__double_as_longlong(key) >> 32);
     hi = (hi & valid_mask) | (0x7FE00000u & ~valid_mask);         // invalid slot: 2^1023 + k
     lo = (lo & valid_mask) | ((uint32_t)k & ~valid_mask);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
@@ -165,12 +175,23 @@ __device__ __noinline__ void sort_order(int list, const float* __restrict__ dept
         }
     };
     auto make_batch = [&](int r0, const float (&v)[16]) {
+        uint32_t nonfinite = 0;                  // running maximum of (value bits << 1): >= 0xFF000000 iff an exponent was all ones
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int r = r0 + u, e = e0 + r;
-            const uint32_t mask = (uint32_t)__builtin_amdgcn_sbfe((int)vw[r >> 5], r & 31, 1);      // v_bfe_i32 of one bit: 0 or all ones
             const float val = e >= WMF_TAPS ? 0.0f : v[u];                                         // the zero slot: value +0 (pads: invalid)
-            key[r] = flip_sign(wmf_key(val, e, mask), sign);
+            key[r] = wmf_key_bits(val, e);
+            nonfinite = max(nonfinite, __float_as_uint(val) << 1);
+        }
+        if (__any(nonfinite >= 0xFF000000u)) {   // rare, wave-uniform
+#pragma unroll
+            for (int u = 0; u < 16; u++) key[r0 + u] = wmf_key_fix_nonfinite(key[r0 + u], e0 + r0 + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int r = r0 + u;
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_sbfe((int)vw[r >> 5], r & 31, 1);      // v_bfe_i32 of one bit: 0 or all ones
+            key[r] = flip_sign(wmf_key_mask(key[r], e0 + r, mask), sign);
         }
     };
     {
@@ -195,23 +216,24 @@ __device__ __noinline__ void sort_order(int list, const float* __restrict__ dept
     // in its negated domain, min(-b_r, -a_r) = -max(a_r, b_r): one instruction sequence for both
 #pragma unroll
     for (int r = 0; r < WMF_HALF; r++) {
-        const double p = flip_sign(partner_of(key[r]), 0x80000000u);
-        asm("v_min_f64 %0, %1, %2" : "=v"(key[r]) : "v"(key[r]), "v"(p));
+        const double p = partner_of(key[r]);
+        asm("v_min_f64 %0, %1, -%2" : "=v"(key[r]) : "v"(key[r]), "v"(p));     // (the negation is the instruction's source modifier)
     }
 #define WMF_NET_MERGE64
 #include "wmf_sort_network.h"
 #undef WMF_NET_MERGE64
 #undef CE
     // rank of register r: r in the first half; 127 - r in the second (its negated keys ascend = the keys descend)
+    const uint32_t slot_flip = half ? 127u : 0u;                  // the slot bits of a NEGATED key are those of the key under the other sign
 #pragma unroll
     for (int r = 0; r < WMF_HALF; r++) {
         const int rank = half ? WMF_ELEMS - 1 - r : r;
-        l.pos[rank * WMF_PIX + pix] = (unsigned char)wmf_key_slot(flip_sign(key[r], sign));
+        l.pos[rank * WMF_PIX + pix] = (unsigned char)((uint32_t)wmf_key_slot(key[r]) ^ slot_flip);
     }
 }
 
-// (clamped: an entry number is at most 127 whatever the byte holds)
-DEVFN int pos_at(const WmfLds& l, int i, int pix) { return min((int)l.pos[i * WMF_PIX + pix], WMF_ELEMS - 1); }
+// (every rank's byte is written by this wave's sort before any walk reads it, and wmf_key_slot masks with 127: no clamp needed)
+DEVFN int pos_at(const WmfLds& l, int i, int pix) { return (int)l.pos[i * WMF_PIX + pix]; }
 // Cumulative weight in rank order (gipuma.cu:1618-1650): acc += w[pos[i]] for i = 0 .. num-1, sequentially — the fp32 sums must
 // be formed in exactly this order.  Each step is an LDS read (the entry) feeding a second LDS read (its weight); the walk goes in
 // batches of 16: the 16 entries, then the 16 weights, are in flight together, and only the adds are sequential.  Both halves of a
@@ -219,12 +241,14 @@ DEVFN int pos_at(const WmfLds& l, int i, int pix) { return min((int)l.pos[i * WM
 // (acc + 0.0f == acc).  The rank at which the sum first reaches `half` is COUNTED, not searched: the weights are >= 0, so the
 // partial sums never decrease and the first i with acc_i >= half is the number of steps with acc_i < half (three instructions per
 // step: add, compare, add-with-carry; the batch's padding steps repeat the last partial sum and are cut off by min(., num)).
-// Returns the total; *below = that count, num if the sum never reaches `half`.
+// Returns the total (TOTAL walks); *below = that count, num if the sum never reaches `half` — the counting walks stop as soon as
+// every pixel of the wave has crossed (the count cannot change after that), about half way on average.
 #define WMF_WALK 16
+template <bool TOTAL>     // TOTAL: walk every rank and return the sum; otherwise stop once every pixel of the wave has crossed `half`
 DEVFN float walk_ranked(const WmfLds& l, int pix, int num, float half, int* below_out) {
     float acc = 0.f;
     int below = 0;
-    for (int i0 = 0; __any(i0 < num); i0 += WMF_WALK) {
+    for (int i0 = 0; TOTAL ? __any(i0 < num) : __any(i0 < num && acc < half); i0 += WMF_WALK) {
         int k[WMF_WALK];
         float wv[WMF_WALK];
 #pragma unroll
@@ -243,7 +267,7 @@ DEVFN float walk_ranked(const WmfLds& l, int pix, int num, float half, int* belo
 // the entry at which the running sum first reaches `half`, or the last walked entry if it never does (gipuma.cu:1618-1650)
 DEVFN int weighted_median_slot(const WmfLds& l, int pix, int num, float half) {
     int below;
-    walk_ranked(l, pix, num, half, &below);
+    walk_ranked<false>(l, pix, num, half, &below);
     return pos_at(l, min(below, num - 1), pix);
 }
 // the two weight tables of WmfLds, by ALL 64 lanes of the workgroup (= one wave): called before any lane leaves the kernel
@@ -304,7 +328,7 @@ DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict_
             // sigma_spatial 2, sigma_color 3 (gipuma.cu:1537-1550): wt = exp(-sd / 4) * exp(-cd / 9), from the tables on 8-bit imagery
             const float cd = fabsf(iv[u] - cen);
             const float ws = l.spatial[min(e, WMF_TAPS - 1)];
-            const float wc = tables ? l.colour[min((int)cd, 255)] : tsar_expf(-cd / 9.0f);
+            const float wc = tables ? l.colour[(int)cd & 255] : tsar_expf(-cd / 9.0f);       // (8-bit imagery: cd is an integer 0..255)
             l.w[e * WMF_PIX + pix] = ok ? ws * wc : 0.f;          // (zero slot and pads: weight 0)
             num += ok ? 1 : 0;
             valid |= (uint64_t)(ok || e == WMF_ZERO) << r;        // the zero slot the reference's sort drags in: always valid
@@ -322,13 +346,13 @@ DEVFN bool median_plane(const DevScene* __restrict__ sc, const float* __restrict
     const DevRef& rf = sc->ref;
     const int num = t.num, w = sc->w, pix = threadIdx.x >> 1;
     sort_order(0, depth_in, n_in, w, sc->h, t, l);
-    const float wsum = walk_ranked(l, pix, num, 0.f, nullptr);
+    const float wsum = walk_ranked<true>(l, pix, num, 0.f, nullptr);
     const float half = wsum / 2.f;
     int weimid = -1;
     {
         // the depth walk breaks at the crossing; without one weimid stays unset (gipuma.cu:1641-1660)
         int below;
-        walk_ranked(l, pix, num, half, &below);
+        walk_ranked<false>(l, pix, num, half, &below);
         if (below < num) {
             const int kf = pos_at(l, below, pix);
             weimid = kf >= WMF_TAPS ? 0 : slot_pixel_safe(t, kf, w, sc->h);   // n[] of the zero slot is 0
