@@ -20,17 +20,18 @@ struct Spixel {   // spixel_info, gSLICr_spixel_info.h:11-17
 };
 
 // pow(x, 1.0f / 3.0f) of rgb2CIELab (shared.h:41-46): the CORRECTLY ROUNDED fp32 value of x^(0.3333333432674407958984375) (the
-// exponent the reference passes is the float nearest 1/3), from IEEE fp64 operations only — the cube root in double-double (Newton,
-// then one step on the exact residual c^3 - x formed with fma) times x^delta, delta = (double)(1.0f / 3.0f) - 1/3, for which ln x is
+// exponent the reference passes is the float nearest 1/3), from IEEE operations only — the cube root in double-double (division-free
+// Newton on the inverse cube root, then one step on the exact residual c^3 - x formed with fma) times x^delta, delta = (double)(1.0f / 3.0f) - 1/3, for which ln x is
 // needed to ~1e-10 only.  Enumerated against powl on every argument an 8-bit colour can produce: 50 329 213 evaluations, 0
 // mismatches (oracle/tsar_oracle_slic.c orc_pow_third_check, the same operation sequence; tests/test_slic_reference_golden.py).
 // The reference compiled on a host calls glibc's powf, which differs from this on 0.07 % of them by one ulp; the Newton cube root
-// of rounds 1-4 differed on 15 %.  ~70 fp64 instructions per evaluation, three per pixel of a quarter-resolution image: < 0.1 ms.
+// of rounds 1-4 differed on 15 %.  Two fp64 divisions per evaluation (seven with the plain Newton of the first version), three evaluations per pixel of a quarter-resolution image.
 DEVFN float pow_third(float xf) {
     const double x = (double)xf;
-    double c = (double)__uint_as_float(__float_as_uint(xf) / 3u + 0x2a5137a0u);
+    double y = (double)(1.0f / __uint_as_float(__float_as_uint(xf) / 3u + 0x2a5137a0u));      // seed of x^(-1/3) from a 5 % cube-root seed
 #pragma unroll
-    for (int i = 0; i < 5; i++) c = c - (c * c * c - x) / (3.0 * (c * c));
+    for (int i = 0; i < 4; i++) y = y * ((4.0 - x * (y * y * y)) * (1.0 / 3.0));             // Newton on y^-3 = x: no division
+    const double c = x * (y * y);
     const double c2 = c * c, e2 = fma(c, c, -c2);
     const double c3 = c2 * c, e3 = fma(c2, c, -c3);
     const double r = (c3 - x) + fma(e2, c, e3);
