@@ -600,6 +600,33 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     m.close()
 
 
+def test_wmf_odd_size_partial_last_workgroup():
+    """173 x 61 = 10 553 pixels: not a multiple of the 32 pixels a workgroup serves (two lanes per pixel), rows that do not align
+    with waves, and — at the fine tap grids — waves whose windows are all inside the image next to waves at the border (the two
+    addressing paths of wmf_kernels.hip): detection and fill bit for bit"""
+    sc = synth.make_scene(173, 61, 2, seed=12)
+    h, w = sc.h, sc.w
+    orc, m = _prepared_pair(sc, 5)
+    rng = np.random.default_rng(3)
+    scale = (rng.uniform(size=(h, w)) < 0.75).astype(np.float32)
+    orc.scale[:] = scale
+    m.set_reliable_mask(scale)
+    labels = np.zeros((h, w), np.int32)
+    text = np.array([1.0], np.float32)
+    orc.set_regions(labels, text)
+    m.set_regions(labels, text)
+    for it in range(4):
+        orc.wmf_detect(it)
+    m.wmf(4, False)
+    assert np.array_equal(m.get_reliable_mask(), orc.scale)
+    for it in range(3):
+        orc.wmf_fill(it)
+    m.wmf(3, True)
+    assert np.array_equal(m.get_plane()[0].view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(m.get_reliable_mask(), orc.scale)
+    m.close()
+
+
 def test_wmf_on_float_imagery_keeps_the_direct_weights(small_scene):
     """the filter's bilateral weight comes from two tables on 8-bit imagery (spatial factor per tap slot, colour factor per integer
     difference: wmf_kernels.hip WmfLds); images that are not an 8-bit decode take the direct form exp(-cd / 9): same oracle, bit for bit"""
