@@ -414,20 +414,10 @@ def test_bench_workload_full_size_first_steps_bit_exact():
     assert rep["all_bit_identical"] is True and rep["steps"][0]["after"] == "pm_init" and rep["steps"][0]["pixels"] == 6048 * 4032
 
 
-@pytest.mark.parametrize("mode", ["fast", "strict"])
-def test_bench_workload_full_size_every_half_sweep_on_windows(mode):
-    """BASELINE configs[1] at its full size (6048x4032, 1 + 10 views, 8 iterations), in the arithmetic bench.py times ("fast":
-    against the oracle's restatement of that arithmetic, oracle/tsar_oracle.c S7, with the device's v_rcp_f32 table) and in the
-    reference's arithmetic ("strict"): EVERY one of the 16 half-sweeps
-    of the run the bench times is checked against the oracle, bit for bit, on twelve 192 x 160 windows of the image (corners,
-    borders, interior: 0.37 Mpixel).  Before each launch the oracle takes the GPU's state (so each launch is judged on its own
-    inputs: propagation reads up to 23 pixels beyond a window), runs the same launch restricted to the windows
-    (orc_pm_sweep_rects: ~0.6 s of 16 host cores instead of a minute for the whole image) and the planes and costs of the swept
-    colour inside the windows must match.  The whole-image version of this comparison is tools/full_size_oracle_check.py
-    (profiles/r02/full_size_oracle_check.json: five iterations, ~2 minutes of oracle time each)."""
+def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed):
+    """every half-sweep of a full-size run against the oracle on twelve 192 x 160 windows (see the tests below)"""
     import torch
-    W, H = 6048, 4032
-    sc = synth.make_scene(W, H, 10, device="cuda", seed=1234)
+    sc = synth.make_scene(W, H, n_src, device="cuda", seed=1234)
     images = [im.cpu().numpy() for im in sc.images]
     orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=11, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY if mode == "fast" else 0)
     m = api.matcher_from_scene(sc, box=11, n_best=1, seed=2024, flags=0 if mode == "fast" else api.FLAG_STRICT_DIV)
@@ -443,7 +433,7 @@ def test_bench_workload_full_size_every_half_sweep_on_windows(mode):
     m.pm_init()
     planes, cost, _, _ = m.get_plane()
     changed = 0
-    for sweep in range(16):
+    for sweep in range(2 * iters):
         colour = sweep & 1
         orc.norm4[...] = planes
         orc.c[...] = cost
@@ -457,10 +447,31 @@ def test_bench_workload_full_size_every_half_sweep_on_windows(mode):
         assert np.array_equal(planes_after[py, px].view(np.uint32), orc.norm4[py, px].view(np.uint32)), "planes differ after half-sweep %d" % sweep
         changed += int((cost_after[py, px] != cost[py, px]).sum())
         planes, cost = planes_after, cost_after
-    assert changed > 100000                  # the sweeps did work inside the windows
+    assert changed > min_changed                  # the sweeps did work inside the windows
     gt = sc.gt_depth.cpu().numpy()
     m.compute_disp()
     depth = m.get_result(("depth",))["depth"]
     assert (np.abs(depth - gt) / gt < 0.01).mean() > 0.99      # and the run converged (bench.py reports the same figure)
     assert not orc.rcp_out_of_range
     m.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_bench_workload_full_size_every_half_sweep_on_windows(mode):
+    """BASELINE configs[1] at its full size (6048x4032, 1 + 10 views, 8 iterations), in the arithmetic bench.py times ("fast":
+    against the oracle's restatement of that arithmetic, oracle/tsar_oracle.c S7, with the device's v_rcp_f32 table) and in the
+    reference's arithmetic ("strict"): EVERY one of the 16 half-sweeps
+    of the run the bench times is checked against the oracle, bit for bit, on twelve 192 x 160 windows of the image (corners,
+    borders, interior: 0.37 Mpixel).  Before each launch the oracle takes the GPU's state (so each launch is judged on its own
+    inputs: propagation reads up to 23 pixels beyond a window), runs the same launch restricted to the windows
+    (orc_pm_sweep_rects: ~0.6 s of 16 host cores instead of a minute for the whole image) and the planes and costs of the swept
+    colour inside the windows must match.  The whole-image version of this comparison is tools/full_size_oracle_check.py
+    (profiles/r02/full_size_oracle_check.json: five iterations, ~2 minutes of oracle time each)."""
+    _every_half_sweep_on_windows(mode, 6048, 4032, 10, 8, 100000)
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_cfg5_full_size_every_half_sweep_on_windows(mode):
+    """BASELINE configs[4] at its full size — 3840 x 2160, 1 + 20 views, 12 iterations: all 24 half-sweeps, both arithmetic modes,
+    bit for bit against the oracle on the same twelve windows (round 4 had this configuration at full size only as a bench record)"""
+    _every_half_sweep_on_windows(mode, 3840, 2160, 20, 12, 100000)
