@@ -414,13 +414,13 @@ def test_bench_workload_full_size_first_steps_bit_exact():
     assert rep["all_bit_identical"] is True and rep["steps"][0]["after"] == "pm_init" and rep["steps"][0]["pixels"] == 6048 * 4032
 
 
-def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed):
+def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed, box=11, n_best=1, converged=0.99):
     """every half-sweep of a full-size run against the oracle on twelve 192 x 160 windows (see the tests below)"""
     import torch
     sc = synth.make_scene(W, H, n_src, device="cuda", seed=1234)
     images = [im.cpu().numpy() for im in sc.images]
-    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=11, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY if mode == "fast" else 0)
-    m = api.matcher_from_scene(sc, box=11, n_best=1, seed=2024, flags=0 if mode == "fast" else api.FLAG_STRICT_DIV)
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=2024, box=box, n_best=n_best, flags=ol.FLAGS_FAST_8BIT_IMAGERY if mode == "fast" else 0)
+    m = api.matcher_from_scene(sc, box=box, n_best=n_best, seed=2024, flags=0 if mode == "fast" else api.FLAG_STRICT_DIV)
     if mode == "fast":
         orc.set_rcp_table(ol.rcp_table_from_device(m))
     rw, rh = 192, 160
@@ -451,7 +451,7 @@ def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed):
     gt = sc.gt_depth.cpu().numpy()
     m.compute_disp()
     depth = m.get_result(("depth",))["depth"]
-    assert (np.abs(depth - gt) / gt < 0.01).mean() > 0.99      # and the run converged (bench.py reports the same figure)
+    assert (np.abs(depth - gt) / gt < 0.01).mean() > converged      # and the run converged (bench.py reports the same figure)
     assert not orc.rcp_out_of_range
     m.close()
 
@@ -475,3 +475,10 @@ def test_cfg5_full_size_every_half_sweep_on_windows(mode):
     """BASELINE configs[4] at its full size — 3840 x 2160, 1 + 20 views, 12 iterations: all 24 half-sweeps, both arithmetic modes,
     bit for bit against the oracle on the same twelve windows (round 4 had this configuration at full size only as a bench record)"""
     _every_half_sweep_on_windows(mode, 3840, 2160, 20, 12, 100000)
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+def test_reference_default_window_full_size_half_sweeps_on_windows(mode):
+    """the reference BINARY's own defaults — box 19 (100 taps), n_best 2 (algorithmparameters.h:25-26), the general-window tap loop of
+    pm_core_lut.h — at the bench workload's full size: the six half-sweeps of three iterations, both modes, bit for bit on the windows"""
+    _every_half_sweep_on_windows(mode, 6048, 4032, 10, 3, 100000, box=19, n_best=2, converged=0.9)
