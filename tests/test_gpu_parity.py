@@ -600,6 +600,37 @@ def test_wmf_detect_and_fill_bit_exact(small_scene):
     m.close()
 
 
+def test_wmf_megapixel_all_tap_grids_interior_and_border():
+    """1216 x 832: at every one of the four detection tap grids (radius 80 / 40 / 20 / 10) and the three fill grids most waves have their
+    whole windows inside the image and read their taps through the scalar-offset buffer loads, the rest through the clamped path
+    (wmf_kernels.hip tap_window); two lanes per pixel; against the oracle's bubble sort, bit for bit (reliability map after the
+    four detection passes, planes / depths / reliability after the three fill passes)"""
+    sc = synth.make_scene(1216, 832, 2, seed=14)
+    h, w = sc.h, sc.w
+    orc, m = _prepared_pair(sc, 6)
+    rng = np.random.default_rng(4)
+    scale = (rng.uniform(size=(h, w)) < 0.7).astype(np.float32)
+    orc.scale[:] = scale
+    m.set_reliable_mask(scale)
+    labels = np.zeros((h, w), np.int32)
+    labels[:, w // 2:] = 1
+    text = np.array([1.0, -1.0], np.float32)
+    orc.set_regions(labels, text)
+    m.set_regions(labels, text)
+    for it in range(4):
+        orc.wmf_detect(it)
+    m.wmf(4, False)
+    got = m.get_reliable_mask()
+    assert np.array_equal(got, orc.scale)
+    assert 0.02 < (got != scale).mean() < 0.98
+    for it in range(3):
+        orc.wmf_fill(it)
+    m.wmf(3, True)
+    assert np.array_equal(m.get_plane()[0].view(np.uint32), orc.norm4.view(np.uint32))
+    assert np.array_equal(m.get_reliable_mask(), orc.scale)
+    m.close()
+
+
 def test_wmf_odd_size_partial_last_workgroup():
     """173 x 61 = 10 553 pixels: not a multiple of the 32 pixels a workgroup serves (two lanes per pixel), rows that do not align
     with waves, and — at the fine tap grids — waves whose windows are all inside the image next to waves at the border (the two
