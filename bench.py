@@ -254,13 +254,16 @@ def choose_backend(world: int, n_devices: int, env=os.environ) -> str:
 def device_identity(index: int) -> dict:
     """what this rank's device IS, for the proof-of-ranks fields of the line: marketing name, gfx arch, and the PCI address / UUID
     that tell two devices apart (whatever of them this torch build exposes)"""
-    p = torch.cuda.get_device_properties(index)
-    ident = {"index": index, "name": p.name, "arch": getattr(p, "gcnArchName", None)}
-    if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
-        ident["pci"] = "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-    if hasattr(p, "uuid"):
-        ident["uuid"] = str(p.uuid)
-    ident["visible"] = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    ident = {"index": index, "name": None, "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
+    try:                                           # (identity is evidence, never a reason for a timed run to fail)
+        p = torch.cuda.get_device_properties(index)
+        ident["name"], ident["arch"] = p.name, getattr(p, "gcnArchName", None)
+        if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            ident["pci"] = "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        if hasattr(p, "uuid"):
+            ident["uuid"] = str(p.uuid)
+    except Exception as e:                         # noqa: BLE001
+        ident["error"] = repr(e)
     return ident
 
 
