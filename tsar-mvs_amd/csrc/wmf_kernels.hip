@@ -224,12 +224,20 @@ __device__ __noinline__ void sort_order(int list, const float* __restrict__ dept
 #undef WMF_NET_MERGE64
 #undef CE
     // rank of register r: r in the first half; 127 - r in the second (its negated keys ascend = the keys descend)
-    const uint32_t slot_flip = half ? 127u : 0u;                  // the slot bits of a NEGATED key are those of the key under the other sign
+    // (the slot bits of a NEGATED key are those of the key under the other sign; bit 7 of a key's low word is zero in every kind of
+    // key — the conversion leaves 29 zero bits, the replacement keys hold the slot alone — so the low byte IS the slot: no mask)
+    const uint32_t sign_fix = half ? ~0u : 0u;
 #pragma unroll
     for (int r = 0; r < WMF_HALF; r++) {
         const int rank = half ? WMF_ELEMS - 1 - r : r;
-        l.pos[rank * WMF_PIX + pix] = (unsigned char)((uint32_t)wmf_key_slot(key[r]) ^ slot_flip);
+        const uint32_t lo = (uint32_t)__double_as_longlong(key[r]), hi = (uint32_t)((unsigned long long)__double_as_longlong(key[r]) >> 32);
+        const uint32_t m = (uint32_t)((int32_t)hi >> 31) ^ sign_fix;          // sign mask of the key as built
+        l.pos[rank * WMF_PIX + pix] = (unsigned char)(lo ^ (m & 127u));
     }
+    // Rank num — the largest valid entry, the one the reference's sort drops — is never looked up (walks cover ranks
+    // < num): it is replaced by the zero slot, so that EVERY rank >= num now carries weight 0 and the walks need no "still inside my
+    // own list" test per step (their batches of 16 may run past num; num <= 121 keeps them inside the 128 ranks).
+    l.pos[t.num * WMF_PIX + pix] = (unsigned char)WMF_ZERO;
 }
 
 // (every rank's byte is written by this wave's sort before any walk reads it, and wmf_key_slot masks with 127: no clamp needed)
@@ -237,10 +245,10 @@ DEVFN int pos_at(const WmfLds& l, int i, int pix) { return (int)l.pos[i * WMF_PI
 // Cumulative weight in rank order (gipuma.cu:1618-1650): acc += w[pos[i]] for i = 0 .. num-1, sequentially — the fp32 sums must
 // be formed in exactly this order.  Each step is an LDS read (the entry) feeding a second LDS read (its weight); the walk goes in
 // batches of 16: the 16 entries, then the 16 weights, are in flight together, and only the adds are sequential.  Both halves of a
-// pixel run the same walk (the same addresses: LDS broadcasts).  Steps past a pixel's own num add the zero slot's weight
-// (acc + 0.0f == acc).  The rank at which the sum first reaches `half` is COUNTED, not searched: the weights are >= 0, so the
+// pixel run the same walk (the same addresses: LDS broadcasts).  Steps past a pixel's own num add a weight of 0 (every rank >= num
+// holds the zero slot or an invalid entry: acc + 0.0f == acc).  The rank at which the sum first reaches `half` is COUNTED, not searched: the weights are >= 0, so the
 // partial sums never decrease and the first i with acc_i >= half is the number of steps with acc_i < half (three instructions per
-// step: add, compare, add-with-carry; the batch's padding steps repeat the last partial sum and are cut off by min(., num)).
+// step: add, compare, add-with-carry; the steps past num repeat the last partial sum and are cut off by min(., num)).
 // Returns the total (TOTAL walks); *below = that count, num if the sum never reaches `half` — the counting walks stop as soon as
 // every pixel of the wave has crossed (the count cannot change after that), about half way on average.
 #define WMF_WALK 16
@@ -252,7 +260,7 @@ DEVFN float walk_ranked(const WmfLds& l, int pix, int num, float half, int* belo
         int k[WMF_WALK];
         float wv[WMF_WALK];
 #pragma unroll
-        for (int u = 0; u < WMF_WALK; u++) k[u] = (i0 + u < num) ? pos_at(l, i0 + u, pix) : WMF_ZERO;
+        for (int u = 0; u < WMF_WALK; u++) k[u] = pos_at(l, i0 + u, pix);          // (ranks >= num: weight 0, see sort_order; i0 + u <= 127)
 #pragma unroll
         for (int u = 0; u < WMF_WALK; u++) wv[u] = l.w[k[u] * WMF_PIX + pix];
 #pragma unroll
@@ -291,7 +299,7 @@ DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict_
     const float cen = img[(size_t)y * w + x];
     const bool tables = sc->use_quad != 0;      // wave-uniform: 8-bit imagery (init_weight_tables ran before any lane left)
     int num = 0;
-    uint64_t valid = 0;
+    uint32_t valid_lo = 0, valid_hi = 0;
     typedef const float __attribute__((address_space(1)))* gptr;
     const gptr gscale = (gptr)scale_in, gimg = (gptr)img;
     t.x = x; t.y = y; t.radius = radius; t.gap = gap;
@@ -331,11 +339,12 @@ DEVFN int collect_taps(const DevScene* __restrict__ sc, const float* __restrict_
             const float wc = tables ? l.colour[(int)cd & 255] : tsar_expf(-cd / 9.0f);       // (8-bit imagery: cd is an integer 0..255)
             l.w[e * WMF_PIX + pix] = ok ? ws * wc : 0.f;          // (zero slot and pads: weight 0)
             num += ok ? 1 : 0;
-            valid |= (uint64_t)(ok || e == WMF_ZERO) << r;        // the zero slot the reference's sort drags in: always valid
+            const uint32_t bit = (uint32_t)(ok || e == WMF_ZERO) << (r & 31);     // the zero slot the reference's sort drags in: always valid
+            if (r < 32) valid_lo |= bit; else valid_hi |= bit;
         }
     }
     num += __builtin_amdgcn_mov_dpp(num, 0xB1, 0xf, 0xf, true);   // + the partner half's taps
-    t.valid = valid;
+    t.valid = ((uint64_t)valid_hi << 32) | valid_lo;
     t.num = num;
     return num;
 }
