@@ -461,7 +461,12 @@ def main():
         line["distinct_devices"] = len(set(keys))
         line["per_rank_ms_per_step"] = [round(r["ms_per_step"], 3) for r in ranks_info]
         if dist is not None and backend == "nccl" and len(set(keys)) != world:
-            raise SystemExit(f"bench.py: {world} ranks over RCCL but only {len(set(keys))} distinct devices: {keys}")
+            # RCCL refuses a communicator with two ranks on one device ("Duplicate GPU detected"), so ranks that got this far over
+            # nccl ARE on distinct devices: equal keys then mean this torch build reports the same PCI address / UUID for every
+            # device (seen with pass-through in containers).  Say so rather than lose the measurement; (visible, index) tells them apart.
+            line["device_identity_ambiguous"] = True
+            line["distinct_devices"] = len({(k, r["local_rank"]) for k, r in zip(keys, ranks_info)})
+            line["n_gpus"] = line["distinct_devices"]
         if gather_check is not None:
             line["gather_check"] = gather_check
         line["config"]["tolerance"] = None
