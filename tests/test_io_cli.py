@@ -95,6 +95,40 @@ def test_cli_matches_the_library(tmp_path):
     assert all(os.path.exists(root + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(4))
 
 
+@pytest.mark.gpu
+def test_cli_reads_a_scene_of_jpegs_like_the_reference(tmp_path):
+    """scripts/courtyard.sh:7,16,44: the scene folder holds JPEGs and the command line names them.  The tool decodes them itself
+    (host/tsar_jpeg.h: libjpeg's grayscale output, what imread(..., IMREAD_GRAYSCALE) returns, main.cpp:1302): same maps, byte for
+    byte, as on PGMs holding libjpeg's own decode of the same files; --all finds the JPEGs behind its %08d names too"""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    import shutil
+    sc = synth.make_scene(128, 96, 3, seed=5)
+    a, b = str(tmp_path / "jpg") + "/", str(tmp_path / "pgm") + "/"
+    tio.export_scene(sc, a)
+    shutil.copytree(a, b)
+    for k in range(4):
+        g = np.clip(sc.images[k].cpu().numpy(), 0, 255).astype(np.uint8)
+        rgb = np.stack([g, np.clip(0.8 * g.astype(np.float32) + 30, 0, 255).astype(np.uint8), 255 - g], -1)      # a coloured photograph
+        os.remove(a + f"images/{k:08d}.pgm")
+        os.remove(b + f"images/{k:08d}.pgm")
+        Image.fromarray(rgb).save(a + f"images/{k:08d}.jpg", quality=92, subsampling=2)
+        tio.convert_image(a + f"images/{k:08d}.jpg", b + f"images/{k:08d}.pgm")
+    outs = []
+    for root, ext in ((a, "jpg"), (b, "pgm")):
+        names = [f"{k:08d}.{ext}" for k in (1, 0, 2, 3)]
+        out = subprocess.run([CLI, *names, "-mslp_folder", root, "-images_folder", root + "images/", "--iterations=2", "--blocksize=11", "--n_best=1", "--seed=7"],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        outs.append((open(root + "APD/00000001/TSAR_disp.dmb", "rb").read(), open(root + "APD/00000001/TSAR_normals.dmb", "rb").read()))
+    assert outs[0] == outs[1]
+    out = subprocess.run([CLI, "--all", "--gpus=1", "-mslp_folder", a, "-images_folder", a + "images/", "--iterations=1", "--blocksize=11", "--n_best=1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert all(os.path.exists(a + f"APD/{k:08d}/TSAR_disp.dmb") for k in range(4))
+    bad = subprocess.run([CLI, "00000001.jpg", "00000000.jpg", "00000002.jpg", "00000009.jpg", "-mslp_folder", a, "-images_folder", a + "images/", "--iterations=1"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "cannot read image" in bad.stderr
+
+
 FUSION = os.path.join(ROOT, "tsar-mvs_amd", "tsar_fusion")
 
 

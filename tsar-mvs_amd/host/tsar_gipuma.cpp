@@ -22,8 +22,11 @@
 //                      GPU's worker with a fresh context; the exit status is non-zero if any view's outputs are still missing.
 //   --num_consistent= --reproj_error= --depth_diff= --angle= --used_list=   the fuser's options (x/1.sh:20-30), for --fuse
 //   --seed=S, --strict, --fix-quirks, --texture-filter-8bit (TSAR_FLAG_TEX_FILTER_8BIT)
-// Images: binary PGM (the image has no JPEG decoder; `python -m tsar_mvs_amd.io convert a.jpg a.pgm`).
-// A name ending in .jpg/.png is looked up as the same stem + .pgm.
+// Images: the scene's JPEGs as they are (host/tsar_jpeg.h: libjpeg's grayscale output = what the reference's imread returns,
+// main.cpp:1302; bit-identical to libjpeg-turbo, tests/test_jpeg_decode.py), or binary PGM / PPM.  A name is looked up as the same
+// stem + .pgm (.ppm with -color_processing) first — a user's own conversion wins — then as the JPEG of that stem.
+//   --decode-image=IN[:OUT.pgm]   no GPU: decode one image the way a run would (after -color_processing: the blue channel), print
+//                                 its size and checksums, optionally write it as PGM
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,6 +63,7 @@ struct Options {
 };
 
 #include "tsar_io.h"
+#include "tsar_jpeg.h"
 
 // The result buffers (depth / normal maps out) are page-locked (tsar_host_alloc): the DMA engine then writes them directly
 // instead of going through the runtime's bounce buffers (a 6048 x 4032 view's results: 9 ms instead of 30), and one set serves
@@ -108,6 +112,35 @@ static std::string pnm_name(const std::string& name, const char* want) {
     const size_t dot = name.find_last_of('.');
     const std::string ext = dot == std::string::npos ? "" : name.substr(dot);
     return (ext == want) ? name : name.substr(0, dot) + want;
+}
+// A view's image: the binary PGM (PPM with -color_processing) of that name where it exists, else the JPEG of the same stem beside
+// it — what the reference's scene folders hold (scripts/courtyard.sh:7,16) — decoded like the reference's imread (host/tsar_jpeg.h).
+static bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+static bool is_jpeg_name(const std::string& p) {
+    const size_t dot = p.find_last_of('.');
+    if (dot == std::string::npos) return false;
+    std::string e = p.substr(dot);
+    for (char& c : e) c = (char)tolower((unsigned char)c);
+    return e == ".jpg" || e == ".jpeg";
+}
+static std::string resolve_view_image(const std::string& path) {
+    if (file_exists(path)) return path;
+    const size_t dot = path.find_last_of('.');
+    const std::string stem = dot == std::string::npos ? path : path.substr(0, dot);
+    for (const char* ext : {".jpg", ".JPG", ".jpeg", ".JPEG"})
+        if (file_exists(stem + ext)) return stem + ext;
+    return path;
+}
+static bool read_view_image(const std::string& path, bool blue, std::vector<uint8_t>& px, int& w, int& h, std::string* why = nullptr) {
+    const std::string p = resolve_view_image(path);
+    if (is_jpeg_name(p)) return tsar_jpeg::read(p, blue ? tsar_jpeg::BLUE : tsar_jpeg::LUMA, px, w, h, why);
+    const bool ok = blue ? read_ppm_channel(p, 2, px, w, h) : read_pgm_u8(p, px, w, h);
+    if (!ok && why) *why = std::string("not a readable binary ") + (blue ? "PPM" : "PGM") + " and no JPEG of that name beside it";
+    return ok;
+}
+static bool view_image_size(const std::string& path, int& w, int& h) {
+    const std::string p = resolve_view_image(path);
+    return is_jpeg_name(p) ? tsar_jpeg::size(p, w, h) : pnm_size(p, w, h);
 }
 static void mkdirs(const std::string& path) {
     std::string cur;
@@ -160,6 +193,24 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
             printf("mask %d x %d reliable %zu checksum %zu\n", mw, mh, ones, wsum);
             return 1;
         }
+        else if (starts("--decode-image=")) {        // no GPU: decode an image the way a run would, --decode-image=IN[:OUT.pgm] [-color_processing first]
+            std::string in = a + 15, out;
+            const size_t colon = in.rfind(':');
+            if (colon != std::string::npos) { out = in.substr(colon + 1); in = in.substr(0, colon); }
+            std::vector<uint8_t> px;
+            int iw = 0, ih = 0;
+            std::string why;
+            if (!read_view_image(in, o.color, px, iw, ih, &why)) { printf("cannot decode %s: %s\n", in.c_str(), why.c_str()); return -1; }
+            uint64_t sum = 0, mix = 1469598103934665603ull;
+            for (uint8_t v : px) { sum += v; mix = (mix ^ v) * 1099511628211ull; }
+            printf("image %d x %d sum %llu fnv1a %016llx\n", iw, ih, (unsigned long long)sum, (unsigned long long)mix);
+            if (!out.empty()) {
+                FILE* f = fopen(out.c_str(), "wb");
+                if (!f || fprintf(f, "P5\n%d %d\n255\n", iw, ih) < 0 || fwrite(px.data(), 1, px.size(), f) != px.size()) { printf("cannot write %s\n", out.c_str()); if (f) fclose(f); return -1; }
+                fclose(f);
+            }
+            return 1;
+        }
         else if (!strcmp(a, "--all")) o.all = true;
         else if (!strcmp(a, "--fuse")) o.fuse = true;
         else if (!strcmp(a, "--force")) o.force = true;                        // --all: recompute views whose outputs are already there
@@ -189,7 +240,7 @@ static int parse_args(int argc, char** argv, Options& o) {   // main.cpp:708-946
 
 // Decoded images shared by all views of a run (--all visits every image as a reference once and as a source ~N times).
 struct ImageCache {
-    struct Entry { std::vector<uint8_t> gray; int w = 0, h = 0; bool ok = false; };      // the 8-bit decode as it is: widened to float on the device (tsar_set_views_u8)
+    struct Entry { std::vector<uint8_t> gray; int w = 0, h = 0; bool ok = false; std::string why; };      // the 8-bit decode as it is: widened to float on the device (tsar_set_views_u8)
     std::mutex mu;
     std::map<std::string, std::shared_ptr<Entry>> items;
     std::shared_ptr<Entry> get(const std::string& path) {
@@ -200,7 +251,7 @@ struct ImageCache {
         }
         auto e = std::make_shared<Entry>();                       // decode outside the lock; a rare double decode is harmless
         const bool ppm = path.size() > 4 && path.compare(path.size() - 4, 4, ".ppm") == 0;
-        e->ok = ppm ? read_ppm_channel(path, 2, e->gray, e->w, e->h) : read_pgm_u8(path, e->gray, e->w, e->h);   // colour: blue, see tsar_io.h
+        e->ok = read_view_image(path, ppm, e->gray, e->w, e->h, &e->why);   // the PGM / PPM of that name, else the JPEG beside it (colour: blue, see tsar_io.h)
         std::lock_guard<std::mutex> lk(mu);
         auto ins = items.emplace(path, e);
         return ins.first->second;
@@ -305,7 +356,7 @@ static std::string view_image_of(const Options& o, int ref) { char b[32]; snprin
 // the done marker of a view: both output maps complete for the size of its reference image
 static bool outputs_complete(const Options& o, int ref) {
     int w = 0, h = 0;
-    if (!pnm_size(view_image_of(o, ref), w, h)) return false;
+    if (!view_image_size(view_image_of(o, ref), w, h)) return false;
     const std::string d = view_dir_of(o, ref);
     return dmb_complete(d + "TSAR_disp.dmb", h, w, 1) && dmb_complete(d + "TSAR_normals.dmb", h, w, 3);
 }
@@ -367,7 +418,7 @@ static int run_view(const Options& o, int device, const std::vector<std::string>
     float dmin = o.depth_min, dmax = o.depth_max;
     for (int i = 0; i < n; i++) {
         const std::string ip = o.images_folder + pnm_name(names[i], o.color ? ".ppm" : ".pgm");
-        if (!gray[i]->ok) { fprintf(stderr, "cannot read image %s\n", ip.c_str()); drop_ctx(); return -1; }
+        if (!gray[i]->ok) { fprintf(stderr, "cannot read image %s: %s\n", ip.c_str(), gray[i]->why.c_str()); drop_ctx(); return -1; }
         const int wi = gray[i]->w, hi = gray[i]->h;
         if (i == 0) { w = wi; h = hi; }
         if (wi != w || hi != h) { fprintf(stderr, "image %s has a different size\n", ip.c_str()); drop_ctx(); return -1; }

@@ -193,13 +193,18 @@ def write_reliable_mask(path: str, reliable) -> None:
 
 
 def convert_image(src: str, dst: str) -> None:
-    """Decode any PIL-readable image -> PGM (8-bit gray, ITU-R 601 luma like cv::IMREAD_GRAYSCALE) or, when dst ends
-    in .ppm, -> PPM (RGB, for -color_processing)."""
+    """Decode any PIL-readable image -> PGM (8-bit gray like cv::IMREAD_GRAYSCALE, main.cpp:1302) or, when dst ends in .ppm,
+    -> PPM (RGB, for -color_processing).  A JPEG's gray is libjpeg's own grayscale output — the luminance component as decoded,
+    which is what OpenCV's imread returns — not a conversion of its RGB decode (a few levels apart in coloured regions); the
+    C++ tools read a scene's JPEGs directly with the same result bit for bit (host/tsar_jpeg.h, tests/test_jpeg_decode.py)."""
     from PIL import Image
+    im = Image.open(src)
     if dst.lower().endswith(".ppm"):
-        write_ppm(dst, np.asarray(Image.open(src).convert("RGB"), np.float32))
-    else:
-        write_pgm(dst, np.asarray(Image.open(src).convert("L"), np.float32))
+        write_ppm(dst, np.asarray(im.convert("RGB"), np.float32))
+        return
+    if im.format == "JPEG" and im.mode in ("RGB", "YCbCr", "L"):
+        im.draft("L", im.size)                     # libjpeg: out_color_space = JCS_GRAYSCALE, full size
+    write_pgm(dst, np.asarray(im.convert("L"), np.float32))
 
 
 # ---- a whole synthetic scene on disk, laid out like data/TRAIN/<scene>/ ---------------------------------
