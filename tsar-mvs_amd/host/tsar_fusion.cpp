@@ -1,7 +1,7 @@
 // tsar_fusion — C++ host tool with the command line of the reference's fuser
 // (x/1.sh:30:  Fusion <mslp_dir> --num_consistent= 1 --reproj_error= 2 --depth_diff= 0.01 --angle= 15 --used_list= 1 ;
 // note the blank after '=' in the reference's scripts — both spellings are accepted).
-// Reads <dir>/pair.txt, <dir>/cams/%08d_cam.txt, <dir>/images/%08d.pgm and, per view,
+// Reads <dir>/pair.txt, <dir>/cams/%08d_cam.txt, <dir>/images/%08d.pgm (else the .jpg of that name) and, per view,
 // <dir>/APD/%08d/TSAR_disp.dmb + TSAR_normals.dmb (what tsar_gipuma / the reference write), fuses them on
 // the GPU (tsar_fuse) and writes <dir>/APD/APD_TSAR.ply (binary little-endian: x y z nx ny nz red green blue).
 #include <stdlib.h>
@@ -10,6 +10,7 @@
 #include <memory>
 
 #include "tsar_io.h"
+#include "tsar_jpeg.h"
 
 int main(int argc, char** argv) {
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
@@ -65,7 +66,13 @@ int main(int argc, char** argv) {
         int h2, w2;
         if (!read_dmb(dir + "APD/" + name + "/TSAR_normals.dmb", normal[k], h2, w2, nb) || nb != 3 || w2 != ww || h2 != hh) { problem[k] = std::string("cannot read APD/") + name + "/TSAR_normals.dmb"; return; }
         int iw, ih;
-        if (!read_pgm(dir + "images/" + name + ".pgm", gray[k], iw, ih) || iw != ww || ih != hh) gray[k].assign((size_t)ww * hh, 128.f);   // colour is cosmetic
+        bool have = read_pgm(dir + "images/" + name + ".pgm", gray[k], iw, ih);
+        for (const char* ext : {".jpg", ".JPG", ".jpeg", ".JPEG"}) {          // the scene's own JPEG (host/tsar_jpeg.h), like tsar_gipuma
+            if (have) break;
+            std::vector<uint8_t> px;
+            if (tsar_jpeg::read(dir + "images/" + name + ext, tsar_jpeg::LUMA, px, iw, ih)) { gray[k].assign(px.begin(), px.end()); have = true; }
+        }
+        if (!have || iw != ww || ih != hh) gray[k].assign((size_t)ww * hh, 128.f);   // colour is cosmetic
         pd[k] = depth[k].data(); pn[k] = normal[k].data(); pg[k] = gray[k].data();
     };
     {
