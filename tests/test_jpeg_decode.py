@@ -130,6 +130,12 @@ def test_what_is_not_supported_is_refused_not_guessed(tmp_path):
     raw = open(p, "rb").read()
     open(p, "wb").write(raw[: len(raw) // 2])        # truncated: libjpeg would pad with gray; a matcher input must not be half an image
     assert "cannot decode" in ours(p, out)
+    Image.fromarray(rgb).save(p, quality=90, progressive=True)
+    raw = open(p, "rb").read()
+    scans = [i for i in range(len(raw) - 1) if raw[i] == 0xFF and raw[i + 1] == 0xDA]
+    assert len(scans) >= 4
+    open(p, "wb").write(raw[: scans[2]] + b"\xff\xd9")   # a progressive file that ends, well-formed, after two scans: libjpeg would smooth its blocks
+    assert "low frequencies" in ours(p, out)
     open(p, "wb").write(b"\x89PNG not a jpeg at all")
     assert "cannot decode" in ours(p, out)
     assert "cannot decode" in ours(str(tmp_path / "missing.jpg"), out)

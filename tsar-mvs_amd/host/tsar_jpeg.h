@@ -137,6 +137,7 @@ struct Component {
     std::vector<uint8_t> plane;      // decoded samples, bw_alloc * 8 wide
     int pred = 0;
     int td = 0, ta = 0;              // tables of the current scan
+    int8_t coef_bits[64];            // progressive: the point transform each coefficient (zigzag index) was last coded with, -1 = never
 };
 
 // clamp(v + 128) as libjpeg's post-IDCT table does it: the argument is taken modulo 1024
@@ -313,6 +314,7 @@ struct Decoder {
             c.hc = (H * c.vs + vmax - 1) / vmax;
             c.bw = (c.wc + 7) / 8; c.bh = (c.hc + 7) / 8;
             c.bw_alloc = mcus_x * c.hs; c.bh_alloc = mcus_y * c.vs;
+            memset(c.coef_bits, -1, sizeof c.coef_bits);
         }
         have_frame = true;
         return true;
@@ -455,6 +457,9 @@ struct Decoder {
             if ((!progressive || !dc_scan) && !ac[sc[i]->ta].set) return fail("scan uses an undefined AC table");
             if (!qt_set[sc[i]->tq]) return fail("component uses an undefined quantisation table");
         }
+        if (progressive)
+            for (int i = 0; i < ns; i++)
+                for (int k = ss; k <= se; k++) sc[i]->coef_bits[k] = (int8_t)al;
         // a progressive AC scan of a component nobody asked for: its entropy-coded bytes are stepped over, not decoded
         if (progressive && !dc_scan && !sc[0]->needed) { pos = next_marker(pos, false); return true; }
         for (int i = 0; i < ncomp; i++) {
@@ -559,7 +564,14 @@ struct Decoder {
             }
         }
         if (!have_frame || !seen_scan) return fail("no image data");
-        if (progressive) finish_progressive();
+        if (progressive) {
+            // libjpeg smooths the blocks of a progressive file whose scans stop before the low frequencies are exact (DC and the
+            // first AC terms): an interrupted transfer, not a matcher input.  Refused rather than reproduced.
+            for (int i = 0; i < ncomp; i++)
+                for (int k = 0; k < 10 && comp[i].needed; k++)
+                    if (comp[i].coef_bits[k] != 0) return fail("progressive JPEG whose scans do not complete the low frequencies (refused)");
+            finish_progressive();
+        }
         return true;
     }
 };
