@@ -414,8 +414,9 @@ def test_bench_workload_full_size_first_steps_bit_exact():
     assert rep["all_bit_identical"] is True and rep["steps"][0]["after"] == "pm_init" and rep["steps"][0]["pixels"] == 6048 * 4032
 
 
-def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed, box=11, n_best=1, converged=0.99):
-    """every half-sweep of a full-size run against the oracle on twelve 192 x 160 windows (see the tests below)"""
+def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed, box=11, n_best=1, converged=0.99, keep=None):
+    """every half-sweep of a full-size run against the oracle on twelve 192 x 160 windows (see the tests below); keep: a subset of
+    the twelve (row-major on the 4 x 3 grid), for the configurations whose oracle time per window is several times the bench workload's"""
     import torch
     sc = synth.make_scene(W, H, n_src, device="cuda", seed=1234)
     images = [im.cpu().numpy() for im in sc.images]
@@ -426,6 +427,8 @@ def _every_half_sweep_on_windows(mode, W, H, n_src, iters, min_changed, box=11, 
     rw, rh = 192, 160
     xs, ys = [0, W // 3 - 7, 2 * W // 3 + 5, W - rw], [0, H // 2 - 3, H - rh]
     rects = [(x, y, x + rw, y + rh) for y in ys for x in xs]
+    if keep is not None:
+        rects = [rects[k] for k in keep]
     mask = np.zeros((H, W), bool)
     for x0, y0, x1, y1 in rects:
         mask[y0:y1, x0:x1] = True
@@ -473,12 +476,13 @@ def test_bench_workload_full_size_every_half_sweep_on_windows(mode):
 @pytest.mark.parametrize("mode", ["fast", "strict"])
 def test_cfg5_full_size_every_half_sweep_on_windows(mode):
     """BASELINE configs[4] at its full size — 3840 x 2160, 1 + 20 views, 12 iterations: all 24 half-sweeps, both arithmetic modes,
-    bit for bit against the oracle on the same twelve windows (round 4 had this configuration at full size only as a bench record)"""
-    _every_half_sweep_on_windows(mode, 3840, 2160, 20, 12, 100000)
+    bit for bit against the oracle on six of the twelve windows — the four corners and the two interior ones (round 4 had this
+    configuration at full size only as a bench record)"""
+    _every_half_sweep_on_windows(mode, 3840, 2160, 20, 12, 50000, keep=(0, 3, 5, 6, 8, 11))
 
 
 @pytest.mark.parametrize("mode", ["fast", "strict"])
 def test_reference_default_window_full_size_half_sweeps_on_windows(mode):
     """the reference BINARY's own defaults — box 19 (100 taps), n_best 2 (algorithmparameters.h:25-26), the general-window tap loop of
-    pm_core_lut.h — at the bench workload's full size: the six half-sweeps of three iterations, both modes, bit for bit on the windows"""
-    _every_half_sweep_on_windows(mode, 6048, 4032, 10, 3, 100000, box=19, n_best=2, converged=0.9)
+    pm_core_lut.h — at the bench workload's full size: the six half-sweeps of three iterations, both modes, bit for bit on six of the windows (corners, interior)"""
+    _every_half_sweep_on_windows(mode, 6048, 4032, 10, 3, 50000, box=19, n_best=2, converged=0.9, keep=(0, 3, 5, 6, 8, 11))
