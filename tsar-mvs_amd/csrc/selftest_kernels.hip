@@ -164,6 +164,76 @@ __global__ __launch_bounds__(256) void sweep_census_kernel(const DevScene* __res
     }
 }
 
+// EXPERIMENT (round 5, measured and removed from the ABI afterwards): how often does an arm's candidate carry a plane this pixel already
+// tried in the previous iteration?  A plane rejected once stays rejected (the cost of a (pixel, plane) pair is fixed and the pixel's
+// cost never rises), so such a hypothesis could be skipped bit-exactly.  memo: 8 hashes per pixel, written for the next call.
+//   out[0] alive arms   out[1] alive arms repeating the same arm's previous plane   out[2] ... any previous arm's plane
+//   out[3] (wave, arm) pairs with an alive lane   out[4] ... in which EVERY alive lane repeats (what the rolled loop could skip)
+//   out[5] sum over waves of max-over-lanes alive arms   out[6] ... of max-over-lanes non-repeating alive arms (lane-local queues)
+__global__ __launch_bounds__(256) void sweep_repeat_kernel(const DevScene* __restrict__ sc, int colour, const float* __restrict__ c, const float4* __restrict__ n4,
+                                                           int tiles_x, int cost_consistent, unsigned long long* __restrict__ memo, unsigned long long* out) {
+    const int tix = blockIdx.x % tiles_x, tiy = blockIdx.x / tiles_x;
+    const int ly = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int y = tiy * 16 + ly;
+    const int x = tix * 32 + 2 * k + ((colour + y) & 1);
+    const int w = sc->w, h = sc->h;
+    const bool live = x < w && y < h;
+    uint32_t alive = 0, rep_same = 0, rep_any = 0;
+    if (live) {
+        const DevRef& rf = sc->ref;
+        int cand[8];
+        select_candidates(sc, c, c, x, y, cand);
+        const size_t p = (size_t)y * w + x;
+        const float4 n_first = n4[p];
+        unsigned long long prev[8], now[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) { prev[a] = memo[p * 8 + a]; now[a] = 0; }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            if (cand[a] < 0) continue;
+            const float4 pl = n4[cand[a] & 0x3fffffff];
+            if (cost_consistent && same_bits(pl, n_first)) continue;
+            const float d = plane_depth(rf, pl, x, y);
+            if (!(d >= rf.depthMin && d <= rf.depthMax)) continue;
+            alive |= 1u << a;
+            unsigned long long hsh = ((unsigned long long)__float_as_uint(pl.x) | ((unsigned long long)__float_as_uint(pl.y) << 32)) * 0x9E3779B97F4A7C15ull;
+            hsh ^= ((unsigned long long)__float_as_uint(pl.z) | ((unsigned long long)__float_as_uint(pl.w) << 32)) * 0xC2B2AE3D27D4EB4Full;
+            hsh |= 1ull;
+            now[a] = hsh;
+            if (prev[a] == hsh) rep_same |= 1u << a;
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (prev[b] == hsh) rep_any |= 1u << a;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++) memo[p * 8 + a] = now[a];
+    }
+    int pairs = 0, pairs_skippable = 0;
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const bool al = (alive >> a) & 1u, fresh = al && !((rep_any >> a) & 1u);
+        if (__any(al)) { pairs++; if (!__any(fresh)) pairs_skippable++; }
+    }
+    int sa = __popc(alive), ss = __popc(rep_same), sy = __popc(rep_any), mx = sa, mf = __popc(alive & ~rep_any);
+    for (int o = 32; o; o >>= 1) {
+        sa += __shfl_xor(sa, o); ss += __shfl_xor(ss, o); sy += __shfl_xor(sy, o);
+        mx = max(mx, __shfl_xor(mx, o)); mf = max(mf, __shfl_xor(mf, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], (unsigned long long)sa); atomicAdd(&out[1], (unsigned long long)ss); atomicAdd(&out[2], (unsigned long long)sy);
+        atomicAdd(&out[3], (unsigned long long)pairs); atomicAdd(&out[4], (unsigned long long)pairs_skippable);
+        atomicAdd(&out[5], (unsigned long long)mx); atomicAdd(&out[6], (unsigned long long)mf);
+    }
+}
+int launch_sweep_repeat(tsar_ctx* ctx, int colour, unsigned long long* memo, unsigned long long* dout) {
+    const DevScene& hs = ctx->hscene;
+    const int tiles_x = (hs.w + 31) / 32, tiles_y = (hs.h + 15) / 16;
+    hipLaunchKernelGGL(sweep_repeat_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, ctx->stream, ctx->dscene, colour, ctx->buf[0].c, ctx->buf[0].n4, tiles_x,
+                       ctx->cost_consistent ? 1 : 0, memo, dout);
+    TSAR_HIP_TRY(ctx, hipGetLastError());
+    return TSAR_OK;
+}
+
 int launch_sweep_census(tsar_ctx* ctx, int colour, unsigned long long* dout) {
     const DevScene& hs = ctx->hscene;
     const int tiles_x = (hs.w + 31) / 32, tiles_y = (hs.h + 15) / 16;

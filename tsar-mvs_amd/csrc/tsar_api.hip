@@ -9,24 +9,23 @@
 #include "tsar_dev.h"
 
 // ---- kernel timing -------------------------------------------------------------------------------
-ScopedKernelTimer::ScopedKernelTimer(tsar_ctx* c, const char* name) : ctx(c) {
-    if (!ctx->timing) return;
-    for (auto& k : ctx->timers)
-        if (k.name == name) t = &k;
-    if (!t) {
+ScopedKernelTimer::ScopedKernelTimer(tsar_ctx* c, const char* name) : ctx(c) {      // name == nullptr: no record
+    if (!ctx->timing || !name) return;
+    for (size_t k = 0; k < ctx->timers.size(); k++)
+        if (ctx->timers[k].name == name) ti = (int)k;
+    if (ti < 0) {
         ctx->timers.emplace_back();
         ctx->timers.back().name = name;
-        t = &ctx->timers.back();
+        ti = (int)ctx->timers.size() - 1;
     }
-    if (hipEventCreate(&e0) != hipSuccess) { t = nullptr; return; }
-    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); t = nullptr; return; }
+    if (hipEventCreate(&e0) != hipSuccess) { ti = -1; return; }
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); ti = -1; return; }
     hipEventRecord(e0, ctx->stream);
 }
 ScopedKernelTimer::~ScopedKernelTimer() {
-    if (!t) return;
+    if (ti < 0) return;
     hipEventRecord(e1, ctx->stream);
-    // vector may have been reallocated between ctor and dtor only by another timer ctor; none nests.
-    t->pending.emplace_back(e0, e1);
+    ctx->timers[ti].pending.emplace_back(e0, e1);
 }
 static void drain_timers(tsar_ctx* ctx) {
     for (auto& k : ctx->timers) {
@@ -250,6 +249,8 @@ static void read_knobs(tsar_ctx* ctx) {
     ctx->strip_w = num("TSAR_STRIP", -1);
     ctx->buffer_from = num("TSAR_BUFFER_FROM", 1);
     ctx->force_block = num("TSAR_BLOCK", 0);
+    ctx->memo_mode = num("TSAR_MEMO", 1);
+    ctx->compact_from = num("TSAR_COMPACT_FROM", 6);
     ctx->lut_mode = num("TSAR_LUT", 1);
     ctx->ransac_wgs = num("TSAR_RANSAC_WGS", 8);
     ctx->ransac_chain = num("TSAR_RANSAC_CHAIN", 8);
@@ -293,6 +294,7 @@ static void free_planes(tsar_ctx* ctx) {
     for (int b = 0; b < 2; b++) { dev_free(ctx->buf[b].c); dev_free(ctx->buf[b].n4); }
     dev_free(ctx->ratio); dev_free(ctx->depth); dev_free(ctx->scale); dev_free(ctx->lrdiff); dev_free(ctx->confid);
     dev_free(ctx->fakedepth); dev_free(ctx->beview); dev_free(ctx->canny); dev_free(ctx->out4);
+    dev_free(ctx->memo_cand); dev_free(ctx->memo_seq); dev_free(ctx->changed_seq);
 }
 
 extern "C" int tsar_destroy(tsar_ctx* ctx) {
@@ -558,7 +560,20 @@ extern "C" int tsar_pm_init(tsar_ctx* ctx) {
 static int pm_sweeps(tsar_ctx* ctx, int n_sweeps, int first_colour, int do_prop, int do_refine) {
     // cur[k]: which ping-pong buffer holds the current values of colour k.  Both start in buf[0].
     int cur[2] = {0, 0};
+    // the propagation memo lives within this call: whatever happened to the state before (init, another subset, loaded planes) is
+    // out of its reach
+    ctx->memo_valid_from = ctx->launch_seq + 1;
+    ctx->call_launch = 0;
+    if (ctx->memo_mode && n_sweeps > 2 && !ctx->memo_cand) {
+        const size_t np = (size_t)ctx->w * ctx->h;
+        TRY(dev_alloc(ctx, &ctx->memo_cand, np * 8));
+        TRY(dev_alloc(ctx, &ctx->memo_seq, np));
+        TRY(dev_alloc(ctx, &ctx->changed_seq, np));
+        TSAR_HIP_TRY(ctx, hipMemsetAsync(ctx->memo_seq, 0, np * sizeof(uint32_t), ctx->stream));
+        TSAR_HIP_TRY(ctx, hipMemsetAsync(ctx->changed_seq, 0, np * sizeof(uint32_t), ctx->stream));
+    }
     for (int s = 0; s < n_sweeps; s++) {
+        ctx->launch_seq++;
         const int colour = (first_colour + s) & 1;
         const PlaneBuf& same_in = ctx->buf[cur[colour]];
         const PlaneBuf& other = ctx->buf[cur[colour ^ 1]];
@@ -566,6 +581,7 @@ static int pm_sweeps(tsar_ctx* ctx, int n_sweeps, int first_colour, int do_prop,
         TRY(launch_pm_sweep(ctx, colour, same_in, other, same_out, 1u + (uint32_t)ctx->sweeps_done, do_prop, do_refine));
         cur[colour] ^= 1;
         ctx->sweeps_done++;
+        ctx->call_launch++;
     }
     // make buf[0] canonical again
     if (cur[0] == 1 && cur[1] == 1) {
@@ -991,6 +1007,22 @@ extern "C" int tsar_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, uint64
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
     scratch.release();
     *mismatches_out = hc;
+    return rc;
+}
+int launch_sweep_repeat(tsar_ctx* ctx, int colour, unsigned long long* memo, unsigned long long* dout);
+extern "C" int tsar_experiment_sweep_repeat(tsar_ctx* ctx, int colour, void* memo_dev, uint64_t* out8) {
+    CHECK_CTX(ctx);
+    NEED_VIEWS(ctx);
+    NEED_STATE(ctx);
+    ScratchScope scratch(ctx);
+    unsigned long long* dc = (unsigned long long*)scratch.alloc(8 * sizeof(unsigned long long));
+    if (!dc) { scratch.release(); return fail(ctx, TSAR_ERR_NOMEM, "device allocation failed"); }
+    int rc = TSAR_OK;
+    if (hipMemsetAsync(dc, 0, 64, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemsetAsync failed");
+    if (rc == TSAR_OK) rc = launch_sweep_repeat(ctx, colour & 1, (unsigned long long*)memo_dev, dc);
+    if (rc == TSAR_OK && hipMemcpyAsync(out8, dc, 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, TSAR_ERR_HIP, "hipMemcpyAsync failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == TSAR_OK) rc = fail(ctx, TSAR_ERR_HIP, "hipStreamSynchronize failed");
+    scratch.release();
     return rc;
 }
 extern "C" int tsar_selftest_sweep_census(tsar_ctx* ctx, int colour, uint64_t* out8) {

@@ -120,6 +120,19 @@ struct tsar_ctx {
     int exact_sqrt_probe = 0;    // the cost tail's square root (sqrt_rsq_exact) on THIS device: 0 not probed yet, 1 holds, -1 failed
     int exact_div_probe = 0;     // strict mode's short exact division on THIS device: 0 not probed yet, 1 holds, -1 failed (probe_exact_divide)
     int sweeps_done = 0;         // RNG stream counter
+    // Propagation memo (pm_sweep_impl.h SweepMemo): per pixel the eight candidates of its previous propagation launch, the number of
+    // that launch, and the number of the last launch that changed the pixel's plane.  A candidate that is the same neighbour as last
+    // time, with a plane unchanged since, was scored at this pixel then and rejected (or taken and since improved on): the pixel's cost
+    // never rises, so it is rejected again and need not be scored — the reference's results, bit for bit, with fewer evaluations.
+    // Valid among the launches of ONE tsar_pm_iterate call only (nothing else touches the state in between).
+    int32_t* memo_cand = nullptr;     // [h][w][8]
+    uint32_t* memo_seq = nullptr;     // [h][w]
+    uint32_t* changed_seq = nullptr;  // [h][w]
+    uint32_t launch_seq = 0;          // sweep launches of this context so far (never reset)
+    uint32_t memo_valid_from = 1;     // memos written before this launch are void
+    int call_launch = 0;              // launches since the current tsar_pm_iterate call began
+    int memo_mode = 1;                // TSAR_MEMO=0: off
+    int compact_from = 6;             // TSAR_COMPACT_FROM=n (-1: never): from launch n of a call on, a wave packs its surviving hypotheses (pm_sweep_impl.h)
     const float* final_text = nullptr;   // device lines->text while tsar_pm_iterate_final runs (the kernels' `final` mode), else null
     // timing
     int variant = 2;             // TSAR_VARIANT=n: code-generation variant of the fast-mode tap loop (pm_core.h view_cost); tsar_create picks 250 (med3/fract + D16 window loads + clamp-free loop for in-image windows + wave priority + SGPR-pinned texture base and line-top weight loads + row-wise window walk in fast mode; strict mode runs it as 122, the oracle's column order) when the D16 probe passes, else 114
@@ -195,7 +208,7 @@ struct ScratchScope {
 // RAII bracket that records a hipEvent pair around a launch when timing is enabled.
 struct ScopedKernelTimer {
     tsar_ctx* ctx;
-    KernelTimer* t = nullptr;
+    int ti = -1;                // index into ctx->timers (timers may nest: the vector can grow between constructor and destructor)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ScopedKernelTimer(tsar_ctx* c, const char* name);
     ~ScopedKernelTimer();
