@@ -323,6 +323,12 @@ int tsar_selftest_divide_random(tsar_ctx* ctx, int log2_triples, uint64_t seed, 
  * evaluations the wave-uniform hypothesis loop of the sweep kernel runs, against what lane-local candidate queues would run
  * (gipuma.cu:553-555 early-outs; selftest_kernels.hip documents the eight counters). */
 int tsar_selftest_sweep_census(tsar_ctx* ctx, int colour, uint64_t* out8);
+/* Census behind the propagation memo: for the half-sweep of `colour` about to run, how many alive arms carry the plane the pixel
+ * tried in the previous call of this function (memo_dev: w * h * 8 uint64 on the device, zeroed before the first call, updated by
+ * each).  out8: [0] alive arms, [1] repeating the same arm's plane, [2] any arm's, [3] (wave, arm) pairs with an alive lane,
+ * [4] of those, pairs in which every alive lane repeats, [5] sum over waves of max-over-lanes alive arms, [6] ... of fresh ones,
+ * [7] sum over waves of ceil(fresh pairs of the wave / 64) = the propagation trips of the packed form. */
+int tsar_selftest_sweep_repeat(tsar_ctx* ctx, int colour, void* memo_dev, uint64_t* out8);
 /* One stage of tsar_slic on caller-supplied HOST arrays, so that a test can hold every SLIC kernel to the outputs of the reference's
  * own per-pixel functions (gSLICr_seg_engine_shared.h:7-204, host-compiled from the reference where it lies: tests/golden/slic_ref.npz).
  * Centres are 32-byte records laid out like the reference's spixel_info (gSLICr_spixel_info.h:11-17: center 2 f32, color_info

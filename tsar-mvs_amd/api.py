@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "tsar_set_region_planes", "tsar_fake_depth", "tsar_fill_textureless",
     "tsar_default_slic_settings", "tsar_slic", "tsar_default_fusion_params", "tsar_fuse", "tsar_fuse_ctx",
     "tsar_host_alloc", "tsar_host_free", "tsar_device_alloc", "tsar_device_free", "tsar_device_write", "tsar_peer_copy", "tsar_enable_kernel_timing", "tsar_reset_kernel_timing", "tsar_get_kernel_timing",
-    "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sqrt", "tsar_selftest_sweep_census", "tsar_selftest_slic_stage",
+    "tsar_selftest_divide", "tsar_selftest_divide_random", "tsar_selftest_sqrt", "tsar_selftest_sweep_census", "tsar_selftest_sweep_repeat", "tsar_selftest_slic_stage",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def load_library(path: str = LIB_PATH):
     L.tsar_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(KernelTiming), C.c_int, C.POINTER(C.c_int)]
     L.tsar_selftest_divide.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     L.tsar_selftest_sweep_census.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.tsar_selftest_sweep_repeat.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     L.tsar_selftest_sqrt.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]
     L.tsar_selftest_divide_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.tsar_selftest_slic_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SlicSettings), C.c_void_p, C.c_void_p, C.c_void_p]

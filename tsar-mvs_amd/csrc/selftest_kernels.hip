@@ -164,12 +164,13 @@ __global__ __launch_bounds__(256) void sweep_census_kernel(const DevScene* __res
     }
 }
 
-// EXPERIMENT (round 5, measured and removed from the ABI afterwards): how often does an arm's candidate carry a plane this pixel already
-// tried in the previous iteration?  A plane rejected once stays rejected (the cost of a (pixel, plane) pair is fixed and the pixel's
-// cost never rises), so such a hypothesis could be skipped bit-exactly.  memo: 8 hashes per pixel, written for the next call.
+// Census behind the propagation memo (pm_sweep_impl.h SweepMemo): how often does an arm's candidate carry a plane this pixel already
+// tried in its previous propagation launch?  A plane rejected once stays rejected (the cost of a (pixel, plane) pair is fixed and the
+// pixel's cost never rises), so such a hypothesis can be skipped bit-exactly.  memo_dev: 8 hashes per pixel, written for the next call.
 //   out[0] alive arms   out[1] alive arms repeating the same arm's previous plane   out[2] ... any previous arm's plane
 //   out[3] (wave, arm) pairs with an alive lane   out[4] ... in which EVERY alive lane repeats (what the rolled loop could skip)
 //   out[5] sum over waves of max-over-lanes alive arms   out[6] ... of max-over-lanes non-repeating alive arms (lane-local queues)
+//   out[7] sum over waves of ceil(non-repeating alive arms of the wave / 64): the trips of the packed form
 __global__ __launch_bounds__(256) void sweep_repeat_kernel(const DevScene* __restrict__ sc, int colour, const float* __restrict__ c, const float4* __restrict__ n4,
                                                            int tiles_x, int cost_consistent, unsigned long long* __restrict__ memo, unsigned long long* out) {
     const int tix = blockIdx.x % tiles_x, tiy = blockIdx.x / tiles_x;
@@ -214,15 +215,16 @@ __global__ __launch_bounds__(256) void sweep_repeat_kernel(const DevScene* __res
         const bool al = (alive >> a) & 1u, fresh = al && !((rep_any >> a) & 1u);
         if (__any(al)) { pairs++; if (!__any(fresh)) pairs_skippable++; }
     }
-    int sa = __popc(alive), ss = __popc(rep_same), sy = __popc(rep_any), mx = sa, mf = __popc(alive & ~rep_any);
+    int sa = __popc(alive), ss = __popc(rep_same), sy = __popc(rep_any), mx = sa, mf = __popc(alive & ~rep_any), sf = mf;
     for (int o = 32; o; o >>= 1) {
-        sa += __shfl_xor(sa, o); ss += __shfl_xor(ss, o); sy += __shfl_xor(sy, o);
+        sa += __shfl_xor(sa, o); ss += __shfl_xor(ss, o); sy += __shfl_xor(sy, o); sf += __shfl_xor(sf, o);
         mx = max(mx, __shfl_xor(mx, o)); mf = max(mf, __shfl_xor(mf, o));
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out[0], (unsigned long long)sa); atomicAdd(&out[1], (unsigned long long)ss); atomicAdd(&out[2], (unsigned long long)sy);
         atomicAdd(&out[3], (unsigned long long)pairs); atomicAdd(&out[4], (unsigned long long)pairs_skippable);
         atomicAdd(&out[5], (unsigned long long)mx); atomicAdd(&out[6], (unsigned long long)mf);
+        atomicAdd(&out[7], (unsigned long long)((sf + 63) >> 6));       // trips of the packed form: the wave's fresh pairs, 64 at a time
     }
 }
 int launch_sweep_repeat(tsar_ctx* ctx, int colour, unsigned long long* memo, unsigned long long* dout) {

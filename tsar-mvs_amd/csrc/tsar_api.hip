@@ -1010,8 +1010,9 @@ extern "C" int tsar_selftest_sqrt(tsar_ctx* ctx, int mode, uint64_t seed, uint64
     return rc;
 }
 int launch_sweep_repeat(tsar_ctx* ctx, int colour, unsigned long long* memo, unsigned long long* dout);
-extern "C" int tsar_experiment_sweep_repeat(tsar_ctx* ctx, int colour, void* memo_dev, uint64_t* out8) {
+extern "C" int tsar_selftest_sweep_repeat(tsar_ctx* ctx, int colour, void* memo_dev, uint64_t* out8) {
     CHECK_CTX(ctx);
+    if (!memo_dev || !out8) return fail(ctx, TSAR_ERR_INVALID, "memo_dev / out8 is NULL");
     NEED_VIEWS(ctx);
     NEED_STATE(ctx);
     ScratchScope scratch(ctx);
