@@ -18,11 +18,11 @@ from tsar_mvs_amd import api, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(scene, env, iters, flags, n_best=1, one_call=True, timing=False):
+def _run(scene, env, iters, flags, n_best=1, one_call=True, timing=False, box=11):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        m = api.matcher_from_scene(scene, box=11, n_best=n_best, seed=77, flags=flags)      # the knobs are read once, by tsar_create
+        m = api.matcher_from_scene(scene, box=box, n_best=n_best, seed=77, flags=flags)      # the knobs are read once, by tsar_create
     finally:
         for k, v in old.items():
             if v is None:
@@ -80,6 +80,19 @@ def test_packed_form_with_two_best_views_and_a_view_subset():
     b, t = _run(sc, {"TSAR_COMPACT_FROM": "2"}, 5, 0, n_best=2, timing=True)
     _same(a, b)
     assert t["pm_sweep_packed"][0] == 8
+
+
+@pytest.mark.parametrize("mode", ["fast", "strict"])
+@pytest.mark.parametrize("box,n_best", [(19, 2), (7, 1), (15, 5)])
+def test_general_window_kernels_packed_form(mode, box, n_best):
+    """the general-window tap loop (pm_core_lut.h: the reference binary's default box 19 / n_best 2, a small window, five best views —
+    the 32-entry selection) through the same memo and packed form"""
+    sc = synth.make_scene(800, 608, 6, seed=11)
+    flags = 0 if mode == "fast" else api.FLAG_STRICT_DIV
+    a, _ = _run(sc, {"TSAR_MEMO": "0"}, 4, flags, n_best=n_best, box=box)
+    b, t = _run(sc, {"TSAR_COMPACT_FROM": "2"}, 4, flags, n_best=n_best, box=box, timing=True)
+    _same(a, b)
+    assert t["pm_sweep_packed"][0] == 6
 
 
 def test_a_changed_subset_voids_the_memo():

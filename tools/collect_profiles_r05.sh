@@ -4,13 +4,14 @@
 # then copy the CSVs named in profiles/r05/README.md).  Same rules as tools/collect_profiles.sh: each --pmc pass is its own run, never
 # combined with a trace domain, <= 8 counters, restricted to the matcher's kernels.  New in round 5: the counters of the RANDOM-PLANE
 # kernels — pm_full_kernel<INIT> (the initialisation) and the first sweep launch of a view — which rounds 1-4 only argued about
-# ("six cache lines per lane, view and hypothesis"): the include regex takes pm_full_kernel as well.
+# ("six cache lines per lane, view and hypothesis"): the include regex takes pm_full_kernel as well.  The PMC passes run one whole view
+# (8 iterations) since the memo / packed launches of the later iterations differ from the early ones.
 set -o pipefail
 O=${1:-gpurun_out/prof5}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}" || exit 1
 mkdir -p "$O"
 B="--no-cpu-baseline --no-host-boundary --no-strict-record"
-P="--steps 1 --warmup 0 --iters 3 $B"
+P="--steps 1 --warmup 0 $B"
 RX="pm_full_kernel|pm_sweep"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py > $O/bench_stats.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES \

@@ -292,21 +292,15 @@ __global__ __launch_bounds__(BLK) void pm_sweep_kernel(const DevScene* __restric
             pown = (sly + vr) * tw + slx + hr;
         };
         auto my_tid = []() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };   // (opaque: what is derived from it is recomputed, not kept)
-        // which arms of this pixel are to be scored: the tests of the rolled loop, up front (the candidates' planes are read again
-        // by whichever lane scores them)
+        // which arms of this pixel are to be scored: every arm that has a candidate the memo did not remove.  The rolled loop's other two
+        // tests wait for the lane that scores the pair and reads the candidate's plane anyway: a depth out of range scores as never
+        // accepted; a plane the pixel already holds is scored like any other and rejected by the strict `<` (2 % of the pairs, against
+        // eight scattered 16-byte reads per pixel up front: measured, profiles/r05/README.md section 12)
         uint32_t fresh = 0;
         if (work && do_prop) {
 #pragma unroll
-            for (int a = 0; a < 8; a++) {
-                const int ci = cand[a];
-                if (ci < 0) continue;
-                const int idx = ci & 0x3fffffff;
-                const float4 n_t = (ci >> 30) ? n_same[idx] : n_other[idx];
-                if (cost_consistent && same_bits(n_t, n_first)) continue;
-                const float d = plane_depth(rf, n_t, x, y);
-                if (!(d >= rf.depthMin && d <= rf.depthMax)) continue;
-                fresh |= 1u << a;
-            }
+            for (int a = 0; a < 8; a++)
+                if (cand[a] >= 0) fresh |= 1u << a;
         }
         if (!work) fresh = 0;
         uint32_t flags = fresh | (work ? 256u : 0u) | (mine ? 512u : 0u);      // bits 0-7 arms, 8 work, 9 mine
@@ -367,6 +361,10 @@ __global__ __launch_bounds__(BLK) void pm_sweep_kernel(const DevScene* __restric
                     etid = wave0 + s;
                 }
                 pixel_of(etid, ex, ey, eown);
+                if (go) {                                   // spatialPropagation_cu gipuma.cu:553: a hypothesis outside [depthMin, depthMax] is never accepted
+                    const float d = plane_depth(rf, n_t, ex, ey);
+                    go = d >= rf.depthMin && d <= rf.depthMax;
+                }
             } else {
                 // planeRefinement_cu gipuma.cu:621-676 + getRndDispAndUnitVector_cu :582-619, every lane on its own pixel
                 pixel_of(etid, ex, ey, eown);
@@ -447,9 +445,9 @@ __global__ __launch_bounds__(BLK) void pm_sweep_kernel(const DevScene* __restric
 }
 
 
-// the box-11 production variants have a packed form (CMP) beside the rolled one
+// the tap loops of 8-bit imagery — box 11's own and the general-window one — have a packed form (CMP) beside the rolled one
 template <int HR, bool QUAD, int V>
-constexpr bool sweep_has_packed_form() { return QUAD && HR == 5 && r5_production_variant(V); }
+constexpr bool sweep_has_packed_form() { return QUAD && ((HR == 5 && r5_production_variant(V)) || (V & 1024) != 0); }
 
 template <int NB, int HR, bool STRICT, bool QUAD, int V = 0, int BLK = PM_BLOCK>
 static int launch_sweep_t(tsar_ctx* ctx, int colour, const PlaneBuf& same_in, const PlaneBuf& other, const PlaneBuf& same_out,
