@@ -444,7 +444,7 @@ def main():
             traffic = traffic_from_profiles(args)
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic["bytes"] if traffic else None, "traffic_source": traffic["source"] if traffic else None,
                                 "kernel": "pm_sweep_kernel", "avg_launch_ms": avg_ms, "launches": launches,
-                                "kernel_note": "two instantiations of the one kernel: <.., 250, 256> (gathers as global loads from the byte texture) for the first sweep launch of a view (random planes), <.., 2228474, 256> (structured buffer loads from the half-float difference texture, v_fma_mix_f32 blend) for the other 15; avg_launch_ms is the mean over all 16 per view = (A + 15 x B) / 16 of a rocprofv3 --stats summary",
+                                "kernel_note": "three instantiations of the one kernel: <.., 250, 256, false> (gathers as global loads from the byte texture) for the first sweep launch of a view (random planes), <.., 2228474, 256, false> (structured buffer loads from the half-float difference texture, v_fma_mix_f32 blend) for the next five, <.., 2228474, 256, true> (the same tap loop, the wave's surviving (pixel, arm) pairs packed 64 per trip: DESIGN.md section 4, propagation memo) for the last ten; avg_launch_ms is the mean over all 16 per view = (A + 5 x B + 10 x C) / 16 of a rocprofv3 --stats summary",
                                 "algorithmic_bytes_per_launch": bytes_per_launch,
                                 "note": "the kernel is FP32-VALU bound (SURVEY 8d: ~970 flop/B; issue-slot accounting in profiles/r01/README.md), so the HBM fraction is small by construction and is reported because the metric asks for it; 'valu' prices the same launch against the 157.3 TFLOP/s FP32 vector peak with the reference's as-written flop count. traffic = committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, converged launches), null if absent"}
             flops_per_launch = alg_flops_per_pixel_iteration(args.views, args.box, float(sc.K[0][0][0]), sc.depth_min) * (w * h / 2.0)
