@@ -11,7 +11,7 @@ W, H, V, IT = 6048, 4032, 10, 8
 sc = synth.make_scene(W, H, V, device=torch.device("cuda", 0), seed=1234, cam_seed=42, step=0.03)
 m = api.matcher_from_scene(sc, box=11, n_best=1, seed=2024)
 L = m.L
-memo = torch.zeros((H * W * 24,), dtype=torch.int64, device="cuda")
+memo = torch.zeros((H * W * 8,), dtype=torch.int64, device="cuda")
 m.pm_init()
 for it in range(IT):
     for colour in (0, 1):
@@ -21,6 +21,6 @@ for it in range(IT):
         o = list(out)
         print(json.dumps({"iter": it, "colour": colour, "alive_arms": o[0], "repeat_same_arm": round(o[1] / max(o[0], 1), 4), "repeat_any_arm": round(o[2] / max(o[0], 1), 4),
                           "wave_arm_pairs": o[3], "pairs_all_lanes_repeat": round(o[4] / max(o[3], 1), 4),
-                          "repeat_3gen": round(o[5] / max(o[0], 1), 4), "lane_queue_fresh_per_wave": round(o[6] / (o[3] / 8.0), 3) if o[3] else None,
+                          "lane_queue_now_per_wave": round(o[5] / (o[3] / 8.0), 3) if o[3] else None, "lane_queue_fresh_per_wave": round(o[6] / (o[3] / 8.0), 3) if o[3] else None,
                           "packed_trips_per_wave": round(o[7] / (o[3] / 8.0), 3) if o[3] else None}), flush=True)
 m.close()

@@ -186,12 +186,9 @@ __global__ __launch_bounds__(256) void sweep_repeat_kernel(const DevScene* __res
         select_candidates(sc, c, c, x, y, cand);
         const size_t p = (size_t)y * w + x;
         const float4 n_first = n4[p];
-        unsigned long long prev[24], now[8];
+        unsigned long long prev[8], now[8];
 #pragma unroll
-        for (int a = 0; a < 24; a++) prev[a] = memo[p * 24 + a];
-#pragma unroll
-        for (int a = 0; a < 8; a++) now[a] = 0;
-        uint32_t rep2 = 0, rep3 = 0;
+        for (int a = 0; a < 8; a++) { prev[a] = memo[p * 8 + a]; now[a] = 0; }
 #pragma unroll
         for (int a = 0; a < 8; a++) {
             if (cand[a] < 0) continue;
@@ -204,31 +201,24 @@ __global__ __launch_bounds__(256) void sweep_repeat_kernel(const DevScene* __res
             hsh ^= ((unsigned long long)__float_as_uint(pl.z) | ((unsigned long long)__float_as_uint(pl.w) << 32)) * 0xC2B2AE3D27D4EB4Full;
             hsh |= 1ull;
             now[a] = hsh;
+            if (prev[a] == hsh) rep_same |= 1u << a;
 #pragma unroll
-            for (int b = 0; b < 8; b++) if (prev[b] == hsh) rep_any |= 1u << a;
-#pragma unroll
-            for (int b = 0; b < 16; b++) if (prev[b] == hsh) rep2 |= 1u << a;
-#pragma unroll
-            for (int b = 0; b < 24; b++) if (prev[b] == hsh) rep3 |= 1u << a;
+            for (int b = 0; b < 8; b++)
+                if (prev[b] == hsh) rep_any |= 1u << a;
         }
-        rep_same = rep2;          // EXPERIMENT: out[1] = two generations, out[5] (below) = three
 #pragma unroll
-        for (int a = 0; a < 16; a++) memo[p * 24 + 8 + a] = prev[a];
-#pragma unroll
-        for (int a = 0; a < 8; a++) memo[p * 24 + a] = now[a];
-        alive |= rep3 << 8;
+        for (int a = 0; a < 8; a++) memo[p * 8 + a] = now[a];
     }
-    const uint32_t rep3m = alive >> 8; alive &= 255u;
     int pairs = 0, pairs_skippable = 0;
 #pragma unroll
     for (int a = 0; a < 8; a++) {
         const bool al = (alive >> a) & 1u, fresh = al && !((rep_any >> a) & 1u);
         if (__any(al)) { pairs++; if (!__any(fresh)) pairs_skippable++; }
     }
-    int sa = __popc(alive), ss = __popc(rep_same), sy = __popc(rep_any), mx = __popc(rep3m), mf = __popc(alive & ~rep_any), sf = __popc(alive & ~rep3m);
+    int sa = __popc(alive), ss = __popc(rep_same), sy = __popc(rep_any), mx = sa, mf = __popc(alive & ~rep_any), sf = mf;
     for (int o = 32; o; o >>= 1) {
         sa += __shfl_xor(sa, o); ss += __shfl_xor(ss, o); sy += __shfl_xor(sy, o); sf += __shfl_xor(sf, o);
-        mx += __shfl_xor(mx, o); mf = max(mf, __shfl_xor(mf, o));
+        mx = max(mx, __shfl_xor(mx, o)); mf = max(mf, __shfl_xor(mf, o));
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out[0], (unsigned long long)sa); atomicAdd(&out[1], (unsigned long long)ss); atomicAdd(&out[2], (unsigned long long)sy);
