@@ -52,9 +52,10 @@ def _same(a, b):
 @pytest.mark.parametrize("shape", ["128-thread workgroups", "256-thread workgroups"])
 def test_memo_and_packed_form_change_no_bit(mode, shape):
     if shape.startswith("128"):
-        sc = synth.make_scene(320, 240, 4, seed=3)             # below SWEEP_SMALL_IMAGE_TILES
+        sc = synth.make_scene(333, 251, 4, seed=3)             # below SWEEP_SMALL_IMAGE_TILES; the last tiles are partial in x and in y
     else:
-        sc = synth.make_scene(2048, 1600, 3, seed=3)           # 6400 tiles of 256 threads; width not a multiple of 32 x 2 lanes' reach: partial waves
+        sc = synth.make_scene(2050, 1590, 3, seed=3)           # 6500 tiles of 256 threads, the last column 2 pixels wide, the last row 6 high:
+                                                               # lanes without a pixel score other lanes' pairs in the packed form
     flags = 0 if mode == "fast" else api.FLAG_STRICT_DIV
     iters = 6
     plain, _ = _run(sc, {"TSAR_MEMO": "0"}, iters, flags)
