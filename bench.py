@@ -446,10 +446,17 @@ def main():
                                 "kernel": "pm_sweep_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                                 "kernel_note": "three instantiations of the one kernel: <.., 250, 256, false> (gathers as global loads from the byte texture) for the first sweep launch of a view (random planes), <.., 2228474, 256, false> (structured buffer loads from the half-float difference texture, v_fma_mix_f32 blend) for the next five, <.., 2228474, 256, true> (the same tap loop, the wave's surviving (pixel, arm) pairs packed 64 per trip: DESIGN.md section 4, propagation memo) for the last ten; avg_launch_ms is the mean over all 16 per view = (A + 5 x B + 10 x C) / 16 of a rocprofv3 --stats summary",
                                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                                "note": "the kernel is FP32-VALU bound (SURVEY 8d: ~970 flop/B; issue-slot accounting in profiles/r01/README.md), so the HBM fraction is small by construction and is reported because the metric asks for it; 'valu' prices the same launch against the 157.3 TFLOP/s FP32 vector peak with the reference's as-written flop count. traffic = committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, converged launches), null if absent"}
+                                "note": "the kernel is FP32-VALU bound (SURVEY 8d: ~970 flop/B; issue-slot accounting in profiles/r01/README.md), so the HBM fraction is small by construction and is reported because the metric asks for it; 'valu' prices the same launch against the 157.3 TFLOP/s FP32 vector peak with the reference's as-written flop count. traffic = committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, mean over a view's launches but the first two), null if absent"}
             flops_per_launch = alg_flops_per_pixel_iteration(args.views, args.box, float(sc.K[0][0][0]), sc.depth_min) * (w * h / 2.0)
             tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            line["roofline"]["valu"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flops_per_launch": flops_per_launch}
+            line["roofline"]["valu"] = {"achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "algorithmic_flops_per_launch": flops_per_launch,
+                                        "note": "ALGORITHMIC flops = what the reference writes for a launch (every arm of every pixel scored). Since the propagation memo (DESIGN.md section 4) the kernel does not "
+                                                "execute all of them: arms whose candidate the pixel already scored and rejected are dropped (0 % in the first iteration, ~68 % in the eighth, bit-identical states), so "
+                                                "this fraction is throughput in the reference's units, not issue-slot utilisation; a launch that scores everything (33.5 ms: the third to sixth of a view) reaches 0.65"}
+            if "pm_sweep_packed" in timing and timing["pm_sweep_packed"][0] > 0:
+                n_p, ms_p = timing["pm_sweep_packed"]
+                line["roofline"]["launch_forms"] = {"rolled": {"launches": launches - n_p, "avg_ms": (total_ms - ms_p) / max(launches - n_p, 1)},
+                                                    "packed": {"launches": n_p, "avg_ms": ms_p / n_p}}
             line["kernel_ms"] = {k: round(v[1] / max(v[0], 1), 4) for k, v in timing.items()}
         # proof of ranks: what the transport saw, gathered from every rank (all_gather_object) — a SCALE line must show N ranks on
         # N distinct devices over "nccl" (= RCCL); a rehearsal shows its shared device and "gloo".  per_rank_ms_per_step is each rank's
