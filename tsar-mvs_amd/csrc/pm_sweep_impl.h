@@ -102,6 +102,16 @@ DEVFN bool same_bits(const float4& a, const float4& b) {
 }
 
 // The propagation memo (tsar_dev.h tsar_ctx::memo_cand): passed by value.
+// Why dropping an arm changes nothing.  spatialPropagation_cu (gipuma.cu:524-566) takes a neighbour's plane iff its score at this
+// pixel is STRICTLY below the pixel's cost, and a sweep changes a pixel's state in no other way than by such a take (refinement
+// :621-676 likewise), so (1) a pixel's cost never rises.  (2) The score of a plane at a pixel is a function of the two, the views and
+// the parameters — nothing the sweeps change — and every form of the tap loop returns the same bits for it.  Say pixel p tried the
+// plane of neighbour q in launch M: whatever happened then — scored and rejected, scored and taken, not scored because p held that
+// very plane or because its depth was out of range, or dropped by this memo (induction) — p's cost after M is at most that score, or
+// the plane can never be taken.  If q's plane has not changed since (changed[q] < M: q's plane at the start of M is its plane now)
+// and q is the arm's candidate again, the reference scores it again and rejects it again by (1) and (2); the memo skips the scoring.
+// It holds while c[p] is the score of n4[p] under the current views (cost_consistent) and only among the launches of one
+// tsar_pm_iterate call (valid_from), so that nothing but sweeps has touched the state between M and now.
 struct SweepMemo {
     int32_t* cand;                   // [pixel][8]: the candidates of the pixel's previous propagation launch
     uint32_t* seq;                   // [pixel]: the launch that wrote them
@@ -114,7 +124,7 @@ struct SweepMemo {
 // One hypothesis of the propagation / refinement loop scored for pixel (x, y): what the loop body shares between its forms.
 // CMP = false: the rolled loop over the eight arms and the refinement steps, each lane scoring its own pixel's hypotheses (a lane
 // whose arm is skipped idles through that arm).
-// CMP = true (launches whose memo removes a good part of the arms — from the third iteration of a run on): the surviving
+// CMP = true (launches whose memo removes a good part of the arms — from the fourth iteration of a run on: TSAR_COMPACT_FROM): the surviving
 // (pixel, arm) pairs of a WAVE are packed, 64 per trip, whichever lanes' pixels they belong to: trip t scores pairs 64 t .. 64 t + 63
 // in arm-major order, lane j scoring pair 64 t + j for its owner, who publishes the pair (its lane, the arm, the candidate) in the
 // wave's LDS slots before the trip and collects the cost (ds_bpermute) after it.  Arms arrive at an owner in increasing order and
