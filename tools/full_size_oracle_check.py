@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--n_best", type=int, default=1)
     ap.add_argument("--mode", choices=["strict", "fast"], default="strict",
                     help="strict: the reference's arithmetic; fast: the default arithmetic against the oracle's restatement of it (S7, device rcp table)")
+    ap.add_argument("--one-call", action="store_true", dest="one_call",
+                    help="the library runs all iterations in ONE tsar_pm_iterate call — what bench.py and the CLI do, with the propagation memo and, "
+                         "from its seventh launch, the packed sweep — and is compared with the oracle after the last one (the oracle scores every arm of every launch)")
     args = ap.parse_args()
     sc = synth.make_scene(args.width, args.height, args.views, device="cuda", seed=1234)
     images = [im.cpu().numpy() for im in sc.images]
@@ -59,7 +62,18 @@ def main():
     t0 = time.perf_counter(); orc.pm_init(); t_cpu = time.perf_counter() - t0
     t0 = time.perf_counter(); m.pm_init(); t_gpu = time.perf_counter() - t0
     ok = compare("pm_init", t_cpu, t_gpu)
-    for it in range(args.iters):
+    if args.one_call:
+        m.enable_kernel_timing(True)
+        t0 = time.perf_counter(); m.pm_iterate(args.iters); t_gpu = time.perf_counter() - t0
+        t_cpu = 0.0
+        for it in range(args.iters):
+            t0 = time.perf_counter(); orc.pm_iterate(1); dt = time.perf_counter() - t0
+            t_cpu += dt
+            print(json.dumps({"oracle iteration": it + 1, "seconds": round(dt, 1)}), file=sys.stderr, flush=True)
+        ok = compare(f"iteration {args.iters}, the library's {args.iters} iterations in one call", t_cpu, t_gpu) and ok
+        kt = m.kernel_timing()
+        report["sweep_launches"] = {"all": kt["pm_sweep"][0], "packed": kt.get("pm_sweep_packed", (0, 0.0))[0]}
+    for it in range(0 if args.one_call else args.iters):
         t0 = time.perf_counter(); orc.pm_iterate(1); t_cpu = time.perf_counter() - t0
         t0 = time.perf_counter(); m.pm_iterate(1); t_gpu = time.perf_counter() - t0
         ok = compare(f"iteration {it + 1}", t_cpu, t_gpu) and ok
