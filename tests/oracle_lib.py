@@ -42,83 +42,118 @@ def build_oracle(force: bool = False) -> str:
 _lib = None
 
 
+class _Partial:
+    """a CDLL whose missing symbols bind to nothing: libtsar_oracle_nofma.so holds tsar_oracle.c only (no SLIC / texture / fusion)"""
+
+    class _Sink:
+        restype = None
+        argtypes = None
+
+    def __init__(self, L):
+        object.__setattr__(self, "_L", L)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._L, name)
+        except AttributeError:
+            return _Partial._Sink()
+
+
+def _bind(L):
+    """prototypes of the oracle's entry points on a loaded library (the default build or the -DORC_NO_FMA one)"""
+    real = L
+    L = _Partial(real)
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.c_int, C.c_int]
+    L.orc_destroy.argtypes = [C.c_void_p]
+    for name in ("c", "norm4", "ratio", "depth", "scale", "lrdiff", "confid", "fakedepth"):
+        fn = getattr(L, "orc_plane_" + name)
+        fn.restype = _f32p
+        fn.argtypes = [C.c_void_p]
+    L.orc_plane_beview.restype = _i32p
+    L.orc_plane_beview.argtypes = [C.c_void_p]
+    L.orc_expf.restype = C.c_float
+    L.orc_expf.argtypes = [C.c_float]
+    L.orc_bilinear.restype = C.c_float
+    L.orc_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.orc_bilinear_q8.restype = C.c_float
+    L.orc_bilinear_q8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.orc_pm_cost.restype = C.c_float
+    L.orc_pm_cost.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_pm_cost_multiview.restype = C.c_float
+    L.orc_pm_cost_multiview.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_getD.restype = C.c_float
+    L.orc_getD.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.orc_depth_from_plane.restype = C.c_float
+    L.orc_depth_from_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.orc_min_disp.restype = C.c_float
+    L.orc_max_disp.restype = C.c_float
+    L.orc_min_disp.argtypes = [C.c_void_p]
+    L.orc_max_disp.argtypes = [C.c_void_p]
+    L.orc_camera_ptr.restype = C.c_void_p
+    L.orc_camera_ptr.argtypes = [C.c_void_p, C.c_int]
+    L.orc_set_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
+    L.orc_derive_cameras.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.orc_rng4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_sweep_rects", "orc_pm_iterate", "orc_pm_iterate_final", "orc_pm_cost_planes",
+              "orc_select_candidates", "orc_homography", "orc_view_vector", "orc_load_planes", "orc_compute_disp",
+              "orc_depth_to_plane", "orc_compute_disp_final", "orc_lrdiff", "orc_getview", "orc_fake_depth",
+              "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch", "orc_wmf_detect", "orc_wmf_fill",
+              "orc_ransac_regions", "orc_slic", "orc_rgb2lab", "orc_philox_raw"):
+        getattr(L, n).restype = None
+    L.orc_region_planes.restype = _f32p
+    L.orc_region_planes.argtypes = [C.c_void_p]
+    L.orc_ransac_points.restype = C.c_int
+    L.orc_ransac_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.orc_pow_third.restype = C.c_float
+    L.orc_pow_third.argtypes = [C.c_float]
+    L.orc_pow_third_check.restype = None
+    L.orc_pow_third_check.argtypes = [C.c_void_p]
+    L.orc_slic_distance.restype = C.c_float
+    L.orc_slic_distance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float]
+    L.orc_slic_blocks_per_spixel.restype = C.c_int
+    L.orc_slic_blocks_per_spixel.argtypes = [C.c_int]
+    for n, at in (("orc_slic_convert", [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+                  ("orc_slic_init_centers", [C.c_void_p, C.c_void_p] + [C.c_int] * 5),
+                  ("orc_slic_find_association", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float]),
+                  ("orc_slic_partials", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
+                  ("orc_slic_finalize", [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+                  ("orc_slic_update_centers", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
+                  ("orc_slic_connectivity", [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+                  ("orc_slic_from_lab", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+                  ("orc_homography_arrays", [C.c_void_p] * 6), ("orc_mat3mul", [C.c_void_p] * 3), ("orc_mat3vec", [C.c_void_p] * 3)):
+        getattr(L, n).restype = None
+        getattr(L, n).argtypes = at
+    L.orc_slic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_refine_steps.restype = C.c_int
+    L.orc_refine_steps.argtypes = [C.c_void_p]
+    L.orc_set_rcp_table.restype = None
+    L.orc_set_rcp_table.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_rcp_out_of_range.restype = C.c_int
+    L.orc_rcp_out_of_range.argtypes = [C.c_void_p]
+    L.orc_rcp_gpu.restype = C.c_float
+    L.orc_rcp_gpu.argtypes = [C.c_void_p, C.c_float]
+    return real
+
+
 def lib():
     global _lib
     if _lib is None:
         build_oracle()
-        L = C.CDLL(ORACLE_SO)
-        L.orc_create.restype = C.c_void_p
-        L.orc_create.argtypes = [C.c_int, C.c_int]
-        L.orc_destroy.argtypes = [C.c_void_p]
-        for name in ("c", "norm4", "ratio", "depth", "scale", "lrdiff", "confid", "fakedepth"):
-            fn = getattr(L, "orc_plane_" + name)
-            fn.restype = _f32p
-            fn.argtypes = [C.c_void_p]
-        L.orc_plane_beview.restype = _i32p
-        L.orc_plane_beview.argtypes = [C.c_void_p]
-        L.orc_expf.restype = C.c_float
-        L.orc_expf.argtypes = [C.c_float]
-        L.orc_bilinear.restype = C.c_float
-        L.orc_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
-        L.orc_bilinear_q8.restype = C.c_float
-        L.orc_bilinear_q8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
-        L.orc_pm_cost.restype = C.c_float
-        L.orc_pm_cost.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.orc_pm_cost_multiview.restype = C.c_float
-        L.orc_pm_cost_multiview.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_getD.restype = C.c_float
-        L.orc_getD.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
-        L.orc_depth_from_plane.restype = C.c_float
-        L.orc_depth_from_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-        L.orc_min_disp.restype = C.c_float
-        L.orc_max_disp.restype = C.c_float
-        L.orc_min_disp.argtypes = [C.c_void_p]
-        L.orc_max_disp.argtypes = [C.c_void_p]
-        L.orc_camera_ptr.restype = C.c_void_p
-        L.orc_camera_ptr.argtypes = [C.c_void_p, C.c_int]
-        L.orc_set_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
-        L.orc_derive_cameras.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float]
-        L.orc_rng4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
-        for n in ("orc_set_image", "orc_set_subset", "orc_pm_init", "orc_pm_sweep", "orc_pm_sweep_rects", "orc_pm_iterate", "orc_pm_iterate_final", "orc_pm_cost_planes",
-                  "orc_select_candidates", "orc_homography", "orc_view_vector", "orc_load_planes", "orc_compute_disp",
-                  "orc_depth_to_plane", "orc_compute_disp_final", "orc_lrdiff", "orc_getview", "orc_fake_depth",
-                  "orc_update_scale", "orc_set_regions", "orc_set_region_planes", "orc_set_launch", "orc_wmf_detect", "orc_wmf_fill",
-                  "orc_ransac_regions", "orc_slic", "orc_rgb2lab", "orc_philox_raw"):
-            getattr(L, n).restype = None
-        L.orc_region_planes.restype = _f32p
-        L.orc_region_planes.argtypes = [C.c_void_p]
-        L.orc_ransac_points.restype = C.c_int
-        L.orc_ransac_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
-        L.orc_pow_third.restype = C.c_float
-        L.orc_pow_third.argtypes = [C.c_float]
-        L.orc_pow_third_check.restype = None
-        L.orc_pow_third_check.argtypes = [C.c_void_p]
-        L.orc_slic_distance.restype = C.c_float
-        L.orc_slic_distance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_float]
-        L.orc_slic_blocks_per_spixel.restype = C.c_int
-        L.orc_slic_blocks_per_spixel.argtypes = [C.c_int]
-        for n, at in (("orc_slic_convert", [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
-                      ("orc_slic_init_centers", [C.c_void_p, C.c_void_p] + [C.c_int] * 5),
-                      ("orc_slic_find_association", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float]),
-                      ("orc_slic_partials", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
-                      ("orc_slic_finalize", [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
-                      ("orc_slic_update_centers", [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
-                      ("orc_slic_connectivity", [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
-                      ("orc_slic_from_lab", [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
-                      ("orc_homography_arrays", [C.c_void_p] * 6), ("orc_mat3mul", [C.c_void_p] * 3), ("orc_mat3vec", [C.c_void_p] * 3)):
-            getattr(L, n).restype = None
-            getattr(L, n).argtypes = at
-        L.orc_slic.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_refine_steps.restype = C.c_int
-        L.orc_refine_steps.argtypes = [C.c_void_p]
-        L.orc_set_rcp_table.restype = None
-        L.orc_set_rcp_table.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_rcp_out_of_range.restype = C.c_int
-        L.orc_rcp_out_of_range.argtypes = [C.c_void_p]
-        L.orc_rcp_gpu.restype = C.c_float
-        L.orc_rcp_gpu.argtypes = [C.c_void_p, C.c_float]
-        _lib = L
+        _lib = _bind(C.CDLL(ORACLE_SO))
     return _lib
+
+
+_lib_nofma = None
+
+
+def lib_nofma():
+    """the whole of tsar_oracle.c with every fmaf() as multiply-then-add, bound like lib(): PatchMatch only"""
+    global _lib_nofma
+    if _lib_nofma is None:
+        nofma_lib()                                   # (builds it when stale)
+        _lib_nofma = _bind(C.CDLL(ORACLE_NOFMA_SO))
+    return _lib_nofma
 
 
 def _p(a):
@@ -143,8 +178,8 @@ class Oracle:
     """Host-side mirror of the matcher state used by the parity tests."""
 
     def __init__(self, images, K, R, t, depth_min, depth_max, box=11, n_best=1, cost_comb=1, flags=0, seed=2024,
-                 cam_scale=1.0, subset=None, box_v=None):
-        L = lib()
+                 cam_scale=1.0, subset=None, box_v=None, nofma=False):
+        L = lib_nofma() if nofma else lib()
         self.L = L
         self.images = [np.ascontiguousarray(np.asarray(im, dtype=np.float32)) for im in images]
         self.h, self.w = self.images[0].shape

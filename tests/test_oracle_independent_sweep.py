@@ -1,0 +1,330 @@
+"""A second, independent restatement of ONE red/black half-sweep — the control flow of rows A7 / A8 / A9 — in numpy float32, written
+from the reference's text (gipuma_checkerboard_spatialProp_cu gipuma.cu:846-1050, spatialPropagation_cu :524-566,
+gipuma_checkerboard_planeRefinement_cu :1053-1094, planeRefinement_cu :621-676, getRndDispAndUnitVector_cu :582-619, getD_cu :71-86,
+getDisparity_cu / getDepthFromPlane3_cu :436-453, getViewVector_cu :97-105, the red/black wrappers :1096-1138) without following
+oracle/tsar_oracle.c's code, against the C oracle's orc_pm_sweep.
+
+gipuma.cu cannot be built here, so nothing pins these rows to outputs of the reference; test_oracle_independent_float64.py
+restates the matching cost a second time, this file the loop around it: which pixels a launch touches, the eight arms in the
+reference's order with their border tests and the two quirks, the strict `<` of the accept test after the depth-range test, that a
+pixel's refinement starts from what its propagation left (the reference runs two kernels, the build one), the four uniforms of a
+refinement step and what they perturb, the running step widths, the disparity the NEXT step starts from (the accepted hypothesis's own,
+not the plane's), `+` in minDelta, the flip to the viewing hemisphere, getD_cu's plane offset.  Shared with the oracle, on purpose: the
+score of a plane at a pixel (orc_pm_cost_multiview — restated independently in the float64 file), the uniforms (Philox, S1 — the
+build's replacement of clock-seeded cuRAND), reads from the launch-start state (S2) and 1 / sqrtf for rsqrtf (S4).
+
+Every expression below is one IEEE operation per operator in the reference's order (numpy float32 scalars), which is what the oracle
+computes when built with -DORC_NO_FMA (every fmaf of its S4 written as multiply-then-add): against that build the restatement must agree
+BIT FOR BIT; against the default build (S4's fused operations) to rounding.  A misreading of the text would have to be made twice, in two
+languages and two loop structures, to go unseen."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from tsar_mvs_amd import synth
+
+f32 = np.float32
+
+
+class _Cam:
+    """Camera_cu of the reference view as the oracle derived it (camera.h:9-33): the fields the sweep reads"""
+
+    def __init__(self, cv):
+        a = lambda v: np.array(list(v), dtype=np.float32)
+        self.K, self.Minv, self.P34, self.C = a(cv.K), a(cv.Minv), a(cv.P34), a(cv.C)
+        self.fx, self.alpha, self.f, self.baseline = f32(cv.fx), f32(cv.alpha), f32(cv.f), f32(cv.baseline)
+        self.depthMin, self.depthMax = f32(cv.depthMin), f32(cv.depthMax)
+
+
+def _matvec(m, v):                                       # matvecmul4, config.h:164-176: m[0] v.x + m[1] v.y + m[2] v.z, left to right
+    return [m[3 * r] * v[0] + m[3 * r + 1] * v[1] + m[3 * r + 2] * v[2] for r in range(3)]
+
+
+def _dot(a, b):                                          # dot4, config.h:36-38 (three components)
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def _depth_of_plane(cam, n4, x, y):                      # getDisparity_cu -> getDepthFromPlane3_cu, gipuma.cu:436-453
+    d = n4[3]
+    if d != d:
+        return f32(1000)
+    den = (n4[0] * (f32(x) - cam.K[2])) + (n4[1] * (f32(y) - cam.K[5])) * cam.alpha + n4[2] * cam.fx
+    return -d * cam.fx / den
+
+
+def _plane_offset(cam, n, x, y, depth):                  # getD_cu, gipuma.cu:71-86
+    pt = [depth * f32(x) - cam.P34[0], depth * f32(y) - cam.P34[1], depth - cam.P34[2]]
+    return -_dot(n, _matvec(cam.Minv, pt))
+
+
+def _normalize(v):                                       # normalize_cu, gipuma.cu:88-95 (rsqrtf -> 1 / sqrtf: S4)
+    inv = f32(1) / np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    return [v[0] * inv, v[1] * inv, v[2] * inv]
+
+
+def _view_vector(cam, x, y):                             # getViewVector_cu :97-105 over get3Dpoint_cu1 :56-66
+    pt = [f32(x) - cam.P34[0], f32(y) - cam.P34[1], f32(1) - cam.P34[2]]
+    v = _matvec(cam.Minv, pt)
+    return _normalize([v[0] - cam.C[0], v[1] - cam.C[1], v[2] - cam.C[2]])
+
+
+def _between(u, lo, hi):                                 # curand_between :113-116
+    return u * (hi - lo) + lo
+
+
+def _arms(c, x, y, cols, rows, quirks=True):
+    """the neighbour each of the eight arms proposes, in the order the reference calls SPATIALPROPAGATION (gipuma.cu:888-1042); c is
+    the cost plane, flat.  None = the arm's border test fails."""
+    p = y * cols + x
+    out = []
+    # up_far :889-902
+    if y > 2:
+        best, at = c[p - 3 * cols], p - 3 * cols
+        for i in range(1, 11):
+            if y > 2 + 2 * i:
+                q = p - 3 * cols - 2 * i * cols
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # down_far :905-918 — the running minimum starts from c[up_far] (quirk; out of the image for y <= 2, where the build defines c[down_far])
+    if y < rows - 3:
+        best = c[p - 3 * cols] if (quirks and y > 2) else c[p + 3 * cols]
+        at = p + 3 * cols
+        for i in range(1, 11):
+            if y < rows - 3 - 2 * i:
+                q = p + 3 * cols + 2 * i * cols
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # left_far :921-934
+    if x > 2:
+        best, at = c[p - 3], p - 3
+        for i in range(1, 11):
+            if x > 2 + 2 * i:
+                q = p - 3 - 2 * i
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # right_far :937-950 — `if (costMin < c[pointTemp])`: walks to the larger cost (quirk)
+    if x < cols - 3:
+        best, at = c[p + 3], p + 3
+        for i in range(1, 11):
+            if x < cols - 3 - 2 * i:
+                q = p + 3 + 2 * i
+                if (best < c[q]) if quirks else (c[q] < best):
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # up_near :953-972
+    if y > 0:
+        near = p - cols
+        best, at = c[near], near
+        for i in range(3):
+            if y > 1 + i and x > i:
+                q = near - (1 + i) * cols - i
+                if c[q] < best:
+                    best, at = c[q], q
+            if y > 1 + i and x < cols - 1 - i:
+                q = near - (1 + i) * cols + i
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # down_near :976-995
+    if y < rows - 1:
+        near = p + cols
+        best, at = c[near], near
+        for i in range(3):
+            if y < rows - 2 - i and x > i:
+                q = near + (1 + i) * cols - i
+                if c[q] < best:
+                    best, at = c[q], q
+            if y < rows - 2 - i and x < cols - 1 - i:
+                q = near + (1 + i) * cols + i
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # left_near :999-1018
+    if x > 0:
+        near = p - 1
+        best, at = c[near], near
+        for i in range(3):
+            if x > 1 + i and y > i:
+                q = near - (1 + i) - i * cols
+                if c[q] < best:
+                    best, at = c[q], q
+            if x > 1 + i and y < rows - 1 - i:
+                q = near - (1 + i) + i * cols
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    # right_near :1022-1041
+    if x < cols - 1:
+        near = p + 1
+        best, at = c[near], near
+        for i in range(3):
+            if x < cols - 2 - i and y > i:
+                q = near + (1 + i) - i * cols
+                if c[q] < best:
+                    best, at = c[q], q
+            if x < cols - 2 - i and y < rows - 1 - i:
+                q = near + (1 + i) + i * cols
+                if c[q] < best:
+                    best, at = c[q], q
+        out.append(at)
+    else:
+        out.append(None)
+    return out
+
+
+def half_sweep(orc, cam, colour, stream, seed, quirks=True):
+    """one launch pair of the reference — gipuma_{black,red}_spatialProp_cu then gipuma_{black,red}_planeRefine_cu — on the pixels with
+    (x + y) % 2 == colour (black: threadIdx.x even <=> p.y even, :1096-1105, i.e. x + y even), every read from the state as the launch
+    found it (S2).  Returns the new (c, norm4, ratio, beview) planes; orc scores, nothing else."""
+    rows, cols = orc.h, orc.w
+    c0, n0 = orc.c.copy(), orc.norm4.copy()
+    c1, n1, r1, b1 = c0.copy(), n0.copy(), orc.ratio.copy(), orc.beview.copy()
+    cf, nf = c0.reshape(-1), n0.reshape(-1, 4)
+    min_disp, max_disp = f32(orc.min_disp), f32(orc.max_disp)
+    for y in range(rows):
+        for x in range(cols):
+            if (x + y) % 2 != colour:
+                continue
+            p = y * cols + x
+            cost_now, norm_now = cf[p], nf[p].copy()
+            disp_now = _depth_of_plane(cam, norm_now, x, y)
+            # ---- propagation :846-1050
+            for q in _arms(cf, x, y, cols, rows, quirks):
+                if q is None:
+                    continue
+                norm_before = nf[q]
+                disp_before = _depth_of_plane(cam, norm_before, x, y)
+                cost_before, beview, ratio = orc.pm_cost_multiview(x, y, norm_before)
+                if disp_before >= cam.depthMin and disp_before <= cam.depthMax:
+                    if f32(cost_before) < cost_now:
+                        disp_now, norm_now, cost_now = disp_before, norm_before.copy(), f32(cost_before)
+                        r1[y, x], b1[y, x] = ratio, beview
+            # ---- refinement :1053-1094 (its kernel re-reads c, norm4 and recomputes the disparity from the plane: the same values)
+            disp_now = _depth_of_plane(cam, norm_now, x, y)
+            vv = _view_vector(cam, x, y)
+            deltaN = f32(1)
+            deltaZ = max_disp / f32(2)
+            step = 0
+            while deltaZ >= f32(0.01):
+                u = ol.rng4(seed, p, stream, step)
+                disp = cam.f * cam.baseline / disp_now                       # disparityDepthConversion_cu :44-46
+                minDelta = -min(deltaZ, min_disp + disp)
+                maxDelta = min(deltaZ, max_disp - disp)
+                dz = _between(u[0], minDelta, maxDelta)
+                dispOut = min(max(disp + dz, min_disp), max_disp)
+                dispOut = cam.f * cam.baseline / dispOut
+                nt = [norm_now[0] + _between(u[1], -deltaN, deltaN), norm_now[1] + _between(u[2], -deltaN, deltaN),
+                      norm_now[2] + _between(u[3], -deltaN, deltaN)]
+                nt = _normalize(nt)
+                if _dot(nt, vv) > f32(0):                                    # vecOnHemisphere_cu :106-112
+                    nt = [-nt[0], -nt[1], -nt[2]]
+                norm_temp = np.array([nt[0], nt[1], nt[2], _plane_offset(cam, nt, x, y, dispOut)], dtype=np.float32)
+                cost_t, beview, ratio = orc.pm_cost_multiview(x, y, norm_temp)
+                if f32(cost_t) < cost_now:
+                    cost_now, disp_now, norm_now = f32(cost_t), dispOut, norm_temp
+                    r1[y, x], b1[y, x] = ratio, beview
+                deltaN = deltaN / f32(4)
+                deltaZ = deltaZ / f32(10)
+                step += 1
+            c1[y, x], n1[y, x] = cost_now, norm_now
+    return c1, n1, r1, b1
+
+
+def random_init(orc, cam, seed):
+    """gipuma_init_cu2, gipuma.cu:678-729, with rndUnitVectorOnHemisphere_cu :134-137 over rndUnitVectorSphereMarsaglia_cu :118-132.  How
+    the rejection loop's uniforms are numbered is the build's own (S1: draw 0 = (disparity, x, y, -) of counter step 0; every further
+    counter step holds two (x, y) attempts; after 16 steps the pole) — the reference draws from a clock-seeded XORWOW sequence."""
+    rows, cols = orc.h, orc.w
+    c1, n1 = np.empty((rows, cols), np.float32), np.empty((rows, cols, 4), np.float32)
+    mind, maxd = f32(orc.min_disp), f32(orc.max_disp)
+    for y in range(rows):
+        for x in range(cols):
+            p = y * cols + x
+            vv = _view_vector(cam, x, y)
+            u = ol.rng4(seed, p, 0, 0)
+            disp_now = _between(u[0], mind, maxd)
+            attempts = [(u[1], u[2])]
+            for call in range(1, 16):
+                w = ol.rng4(seed, p, 0, call)
+                attempts += [(w[0], w[1]), (w[2], w[3])]
+            a = b = total = f32(0)                                          # (what the build defines when every attempt is rejected)
+            for ua, ub in attempts:
+                xa, xb = _between(ua, f32(-1), f32(1)), _between(ub, f32(-1), f32(1))
+                t = xa * xa + xb * xb                                       # get_pow2_norm, config.h:30
+                if not (t >= f32(1)):
+                    a, b, total = xa, xb, t
+                    break
+            sq = np.sqrt(f32(1) - total)
+            n = [f32(2) * a * sq, f32(2) * b * sq, f32(1) - f32(2) * total]
+            if _dot(n, vv) > f32(0):
+                n = [-n[0], -n[1], -n[2]]
+            depth = cam.f * cam.baseline / disp_now
+            n4 = np.array([n[0], n[1], n[2], _plane_offset(cam, n, x, y, depth)], dtype=np.float32)
+            n1[y, x] = n4
+            c1[y, x] = orc.pm_cost_multiview(x, y, n4)[0]                   # (odd boxes: the init window box / 2 is the sweeps' (box - 1) / 2)
+    return c1, n1
+
+
+def _scene_and_oracle(nofma, flags=0, w=40, h=30, views=3, box=7, n_best=1):
+    sc = synth.make_scene(w, h, views, seed=5)
+    images = [im.cpu().numpy() for im in sc.images]
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=77, box=box, n_best=n_best, flags=flags, nofma=nofma)
+    return sc, orc
+
+
+# flags: the reference's quirks 1 / 2 as written (0), and both fixed (TSAR_FLAG_FIX_*: 3); the scripts' window with the best two of four views
+@pytest.mark.parametrize("flags,views,box,n_best", [(0, 3, 7, 1), (3, 3, 7, 1), (0, 5, 11, 2)])
+def test_two_iterations_against_the_restatement_bit_for_bit(flags, views, box, n_best):
+    sc, orc = _scene_and_oracle(nofma=True, flags=flags, views=views, box=box, n_best=n_best)
+    cam = _Cam(orc.camera(0))
+    c_init, n_init = random_init(orc, cam, seed=77)
+    orc.pm_init()
+    assert np.array_equal(orc.norm4.view(np.uint32), n_init.view(np.uint32))
+    assert np.array_equal(orc.c.view(np.uint32), c_init.view(np.uint32))
+    d0 = np.array([[_depth_of_plane(cam, orc.norm4[y, x], x, y) for x in range(orc.w)] for y in range(orc.h)])
+    assert (d0 > cam.depthMin * 0.999).all() and (d0 < cam.depthMax * 1.001).all()      # every initial plane passes through its pixel's ray inside the range
+    launch = 0
+    changed = 0
+    for it in range(2):
+        for colour in (0, 1):                   # black then red, gipuma.cu:1744-1751
+            c1, n1, r1, b1 = half_sweep(orc, cam, colour, stream=1 + launch, seed=77, quirks=(flags == 0))
+            before = orc.norm4.copy()
+            orc.pm_sweep(colour)
+            launch += 1
+            assert np.array_equal(orc.c.view(np.uint32), c1.view(np.uint32))
+            assert np.array_equal(orc.norm4.view(np.uint32), n1.view(np.uint32))
+            assert np.array_equal(orc.beview, b1)
+            assert np.array_equal(orc.ratio.view(np.uint32), r1.view(np.uint32))
+            other = (np.add.outer(np.arange(orc.h), np.arange(orc.w)) % 2) != colour
+            assert np.array_equal(before[other], orc.norm4[other])                   # the other colour is not touched
+            changed += int((before != orc.norm4).any(-1).sum())
+    assert changed > orc.h * orc.w // 2          # the sweeps did something
+
+
+def test_default_build_agrees_to_rounding():
+    """the oracle as the parity tests use it (S4's fused operations in the plane / depth helpers): same decisions wherever two costs are
+    not within rounding of each other"""
+    sc, orc = _scene_and_oracle(nofma=False)
+    cam = _Cam(orc.camera(0))
+    orc.pm_init()
+    c1, n1, r1, b1 = half_sweep(orc, cam, 0, stream=1, seed=77)
+    orc.pm_sweep(0)
+    same = (np.abs(orc.norm4 - n1).max(-1) < 1e-4) & (np.abs(orc.c - c1) < 1e-5)
+    assert same.mean() > 0.995
