@@ -10,7 +10,10 @@
  * outputs, and those two files cannot be built in this image (they need nvcc, the CUDA headers/runtime, cuRAND and
  * OpenCV; none are present and stand-ins for them are not allowed).  This file is therefore pinned by analytic known answers
  * authored in tests/ (a plane that truly generated the images scores ~0, homography of a fronto-parallel plane is the expected
- * translation, plane<->depth round trips, etc.), not by outputs of gipuma.cu.
+ * translation, plane<->depth round trips, etc.), not by outputs of gipuma.cu — and by a second restatement written from the
+ * reference's text in another language and loop structure (tests/test_oracle_independent_float64.py: the matching cost, numpy
+ * float64; tests/test_oracle_independent_sweep.py: init, the eight arms, the accept tests and the refinement steps, numpy float32,
+ * bit for bit against this file built with -DORC_NO_FMA).
  * PINNED BY THE REFERENCE ITSELF are the two pieces of it that a host compiler takes as they stand (oracle/Makefile `ref`,
  * built from the sources where they lie; outputs recorded by tests/golden/make_slic_ref_golden.py):
  *   - config.h:60-240, the 3x3 array macros getHomography_cu is made of (outer_product, matdivide, matmatsub2, matmul_cu,
