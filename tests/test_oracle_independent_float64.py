@@ -7,7 +7,9 @@ this file adds is a restatement that shares no code, no language, no precision a
 the text would have to be made twice, in two different shapes, to go unseen.  The two agree to the rounding of fp32 (the oracle
 accumulates 36 taps in fp32; the cancellation in E[x^2] - E[x]^2 amplifies that): |cost difference| p50 4e-6, p99 4e-5, max 1e-4 measured
 (the same size as the library's fast-vs-strict arithmetic difference), and the
-minimum-variance cut-off (cost = 2) is taken by the same pixels except where a variance sits within rounding of 1e-5."""
+minimum-variance cut-off (cost = 2) is taken by the same pixels except where a variance sits within rounding of 1e-5.
+Row A11 the same way (rlCost :300-392, gipuma_getlrdiff :1160-1186, gipuma_getview :1188-1213): |lrdiff difference| p50 4e-6, p99 4e-5, max 1.9e-4 on
+the 99 % of the pixels none of whose taps sits within 1e-3 px of an integer-truncation boundary."""
 import numpy as np
 import pytest
 
@@ -155,3 +157,91 @@ def test_homography_against_float64(small_scene):
             H32 = orc.homography(view, n4).astype(np.float64)
             # fp32 through two 3x3 products with intrinsics of magnitude ~50: a few 1e-6 (measured 4.5e-6)
             assert np.max(np.abs(H32 - H64)) <= 2e-5 * np.max(np.abs(H64)) + 1e-5
+
+
+def rl_cost_float64(images, cams, view, planes, radius):
+    """rlCost, gipuma.cu:300-392, of every pixel's plane through one source view, float64: the window is laid around the INTEGER-truncated
+    warped point in the source image (`make_int2(pt_c.x + i, pt_c.y + j)`, :355), its taps are exact source texels, each is carried
+    back to the reference image through the inverse homography (the adjugate over the determinant, :316-337) and sampled bilinearly there;
+    the weights compare source texels with the bilinear source sample at the warped point itself.  Returns (cost, smaller variance,
+    distance of the warped point's coordinates from the nearest truncation boundary)."""
+    ref = images[0].astype(np.float64)
+    src = images[view].astype(np.float64)
+    h, w = ref.shape
+    K0, _, _ = cams[0]
+    Kv, Rv, tv = cams[view]
+    n, d = planes[..., :3].astype(np.float64), planes[..., 3].astype(np.float64)
+    M = Rv[None, None] - tv[None, None, :, None] * n[:, :, None, :] / d[:, :, None, None]
+    H = Kv[None, None] @ M @ np.linalg.inv(K0)[None, None]
+    V = np.linalg.inv(H)
+    ys, xs = np.mgrid[0:h, 0:w]
+    Z = H[..., 2, 0] * xs + H[..., 2, 1] * ys + H[..., 2, 2]
+    cx = (H[..., 0, 0] * xs + H[..., 0, 1] * ys + H[..., 0, 2]) / Z
+    cy = (H[..., 1, 0] * xs + H[..., 1, 1] * ys + H[..., 1, 2]) / Z
+    cen = _bilinear_clamped(src, cx, cy)
+    offs = range(-radius, radius + 1, 2)
+    acc = {k: np.zeros((h, w)) for k in ("w", "r", "rr", "s", "ss", "rs")}
+    margin = np.full((h, w), np.inf)
+    with np.errstate(all="ignore"):
+        for i in offs:
+            for j in offs:
+                fx, fy = cx + i, cy + j
+                px, py = np.trunc(fx), np.trunc(fy)                       # float -> int conversion: toward zero
+                margin = np.minimum(margin, np.minimum(np.abs(fx - np.rint(fx)), np.abs(fy - np.rint(fy))))
+                # `ref_pix` of the text is the SOURCE image's texel (texture r), `src_pix` the reference image's sample (texture l)
+                a = src[np.clip(py, 0, h - 1).astype(int), np.clip(px, 0, w - 1).astype(int)]
+                Zb = V[..., 2, 0] * px + V[..., 2, 1] * py + V[..., 2, 2]
+                bx = (V[..., 0, 0] * px + V[..., 0, 1] * py + V[..., 0, 2]) / Zb
+                by = (V[..., 1, 0] * px + V[..., 1, 1] * py + V[..., 1, 2]) / Zb
+                b = _bilinear_clamped(ref, bx, by)
+                wt = np.exp(-np.sqrt(float(i * i + j * j)) / (2.0 * 5.0 * 5.0) - np.abs(a - cen) / (2.0 * 3.0 * 3.0))
+                acc["w"] += wt
+                acc["r"] += wt * a
+                acc["rr"] += wt * a * a
+                acc["s"] += wt * b
+                acc["ss"] += wt * b * b
+                acc["rs"] += wt * a * b
+        m = {k: acc[k] / acc["w"] for k in ("r", "rr", "s", "ss", "rs")}
+        var_r, var_s = m["rr"] - m["r"] ** 2, m["ss"] - m["s"] ** 2
+        c = np.clip(1.0 - (m["rs"] - m["r"] * m["s"]) / np.sqrt(var_r * var_s), 0.0, 2.0)
+    low = (var_r < 1e-5) | (var_s < 1e-5)
+    return np.where(low, 2.0, c), np.minimum(var_r, var_s), margin
+
+
+@pytest.mark.parametrize("box", [11, 7])
+def test_lrdiff_and_confidence_against_the_float64_restatement(small_scene, box):
+    """gipuma_getlrdiff :1160-1186 and gipuma_getview :1188-1213 after two iterations: |c - rlCost through the best view|, capped at 1;
+    confidence ((2 - c) / 2 + (1 - lrdiff)) / 2; depth of the plane"""
+    sc = small_scene
+    images = [im.numpy() for im in sc.images]
+    cams = _reorigin(sc.K, sc.R, sc.t)
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, box=box, n_best=1, seed=3)
+    orc.pm_init()
+    orc.pm_iterate(2)
+    planes, cost, bv = orc.norm4.copy(), orc.c.astype(np.float64), orc.beview.copy()
+    orc.lrdiff_op()
+    orc.getview()
+    got = orc.lrdiff.astype(np.float64)
+    checked = 0
+    for view in (1, 2, 3):
+        rc, vmin, margin = rl_cost_float64(images, cams, view, planes, (box - 1) // 2)
+        want = np.minimum(np.abs(cost - rc), 1.0)
+        # leave out what fp32 decides differently for reasons of rounding alone: a tap within 1e-3 px of a truncation boundary, a variance
+        # within rounding of the cut-off
+        sure = (bv == view) & (margin > 1e-3) & (np.abs(vmin - 1e-5) > 1e-3 * np.maximum(vmin, 1e-5) + 5e-3)
+        assert sure.sum() > 0.15 * sure.size, (view, sure.mean())
+        d = np.abs(got - want)[sure]
+        assert np.percentile(d, 50) <= 2e-5 and np.percentile(d, 99) <= 5e-4, (view, np.percentile(d, [50, 99]))
+        assert (d <= 4e-2 / vmin[sure] + 2e-4).all(), (view, d.max())
+        checked += int(sure.sum())
+    assert checked > 0.8 * bv.size
+    conf = ((2.0 - cost) / 2.0 + (1.0 - got)) / 2.0
+    assert np.abs(orc.confid - conf).max() <= 1e-6
+    # lines->depth after getview (:1207-1210): the depth of the plane at its pixel, -d fx / (n_x (x - cx) + n_y (y - cy) alpha + n_z fx)
+    # (getDepthFromPlane3_cu :436-442), put through disparityDepthConversion_cu ONCE: the plane holds f * baseline / depth, a disparity
+    K0 = cams[0][0]
+    ys, xs = np.mgrid[0:sc.h, 0:sc.w]
+    p64 = planes.astype(np.float64)
+    depth = -p64[..., 3] * K0[0, 0] / (p64[..., 0] * (xs - K0[0, 2]) + p64[..., 1] * (ys - K0[1, 2]) * (K0[0, 0] / K0[1, 1]) + p64[..., 2] * K0[0, 0])
+    cam0 = orc.camera(0)
+    assert np.abs(orc.depth * depth / (float(cam0.f) * float(cam0.baseline)) - 1.0).max() <= 1e-5
