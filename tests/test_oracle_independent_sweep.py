@@ -328,3 +328,93 @@ def test_default_build_agrees_to_rounding():
     orc.pm_sweep(0)
     same = (np.abs(orc.norm4 - n1).max(-1) < 1e-4) & (np.abs(orc.c - c1) < 1e-5)
     assert same.mean() > 0.995
+
+
+# ---- rows A10 / A12: the plane <-> depth kernels and the textureless fill, the same way ----
+
+def test_plane_depth_kernels_and_textureless_fill_bit_for_bit():
+    """host fill main.cpp:1479-1490 + gipuma_get_disp gipuma.cu:731-755, gipuma_compute_disp :810-844, gipuma_dptow :1140-1158,
+    gipuma_update_scale :1215-1259, gipuma_update_scale_2 :1261-1292 — per-pixel numpy float32 from the text against the oracle built
+    without fused operations"""
+    sc, orc = _scene_and_oracle(nofma=True, w=36, h=26)
+    cv = orc.camera(0)
+    cam = _Cam(cv)
+    Rorig, RorigInv = np.array(list(cv.Rorig), np.float32), np.array(list(cv.RorigInv), np.float32)
+    rows, cols = orc.h, orc.w
+    rng = np.random.default_rng(9)
+    depth_in = rng.uniform(sc.depth_min, sc.depth_max, (rows, cols)).astype(np.float32)
+    nw = rng.normal(size=(rows, cols, 3)).astype(np.float32)
+    nw /= np.linalg.norm(nw, axis=-1, keepdims=True).astype(np.float32)
+    fb = cam.f * cam.baseline
+
+    # get_disp: lines->depth was filled with f b / depth (main.cpp:1488), lines->norm4 with the world normal; the kernel rotates the
+    # normal by R_orig and takes the offset of the plane through the pixel's ray at f b / lines->depth
+    orc.load_planes(depth_in, nw)
+    want = np.empty((rows, cols, 4), np.float32)
+    held = np.empty((rows, cols), np.float32)
+    for y in range(rows):
+        for x in range(cols):
+            n = _matvec(Rorig, nw[y, x])
+            held[y, x] = fb / depth_in[y, x]
+            want[y, x] = [n[0], n[1], n[2], _plane_offset(cam, n, x, y, fb / held[y, x])]
+    assert np.array_equal(orc.norm4.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(orc.depth.view(np.uint32), held.view(np.uint32))
+    assert (orc.c == 1.0).all()                                               # main.cpp:1490
+
+    # compute_disp: (R_orig_inv n, depth of the plane at the pixel), depth 0 where the cost is MAXCOST
+    orc.c[3, 4] = 2.0
+    out = orc.compute_disp()
+    for y in range(rows):
+        for x in range(cols):
+            n4 = orc.norm4[y, x]
+            o = _matvec(RorigInv, n4)
+            d = _depth_of_plane(cam, n4, x, y) if orc.c[y, x] != f32(2) else f32(0)
+            assert np.array_equal(np.array([o[0], o[1], o[2], d], np.float32).view(np.uint32), out[y, x].view(np.uint32)), (x, y)
+    assert out[3, 4, 3] == 0.0 and np.abs(out[..., 3][orc.c != 2.0] / depth_in[orc.c != 2.0] - 1.0).max() < 1e-4      # the round trip returns the depths put in
+
+    # update_scale: a pixel of a region flagged -1 takes the region's plane, turned to face the camera (all four components negated), cost 0,
+    # scale 1; EVERY pixel's lines->depth becomes f b / (depth of its plane).  update_scale_2: fakedepth of the flagged regions' planes
+    labels = (np.arange(rows)[:, None] // 9 * 4 + np.arange(cols)[None] // 9).astype(np.int32)
+    n_regions = int(labels.max()) + 1
+    text = np.where(np.arange(n_regions) % 3 == 0, -1.0, 1.0).astype(np.float32)
+    planes = np.empty((n_regions, 4), np.float32)
+    for r in range(n_regions):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        n = n.astype(np.float32)
+        ys, xs = np.nonzero(labels == r)
+        planes[r] = [n[0], n[1], n[2], _plane_offset(cam, n, int(xs[0]), int(ys[0]), f32(0.5 * (sc.depth_min + sc.depth_max)))]
+    before = orc.norm4.copy()
+    c_before = orc.c.copy()
+    orc.set_regions(labels, text)
+    orc.set_region_planes(planes)
+    orc.fake_depth()
+    fake = orc.fakedepth.copy()
+    orc.update_scale()
+    flipped = 0
+    for y in range(rows):
+        for x in range(cols):
+            r = labels[y, x]
+            n4 = before[y, x]
+            if text[r] == -1:
+                vv = _view_vector(cam, x, y)
+                n4 = planes[r].copy()
+                if n4[0] * vv[0] + n4[1] * vv[1] + n4[2] * vv[2] > f32(0):
+                    n4 = -n4
+                    flipped += 1
+                assert orc.c[y, x] == 0.0 and orc.scale[y, x] == 1.0
+                assert np.array_equal(np.array([_depth_of_plane(cam, n4, x, y)], np.float32).view(np.uint32), fake[y, x:x + 1].view(np.uint32))
+            else:
+                assert orc.c[y, x] == c_before[y, x]
+            assert np.array_equal(orc.norm4[y, x].view(np.uint32), n4.view(np.uint32)), (x, y)
+            assert np.array_equal(np.array([fb / _depth_of_plane(cam, n4, x, y)], np.float32).view(np.uint32), orc.depth[y, x:x + 1].view(np.uint32))
+    assert flipped > 0
+
+    # dptow: the offset of the plane through the pixel's ray at f b / lines->depth, normal kept
+    orc.depth[...] = (fb / depth_in).astype(np.float32)
+    kept = orc.norm4.copy()
+    orc.depth_to_plane()
+    for y in range(rows):
+        for x in range(cols):
+            w = _plane_offset(cam, kept[y, x, :3], x, y, fb / orc.depth[y, x])
+            assert np.array_equal(orc.norm4[y, x].view(np.uint32), np.array([*kept[y, x, :3], w], np.float32).view(np.uint32)), (x, y)
