@@ -60,7 +60,7 @@
 #define ORC_FLAG_TEX_FILTER_8BIT (1u << 5)
 #define ORC_FLAG_FIX_INIT_RADIUS (1u << 6) /* gipuma_init_cu2 on the sweeps' window instead of its own box / 2 (gipuma.cu:693-694) */
 /* S7: the arithmetic of the HIP library's default ("fast") mode, restated so that the mode bench.py times can be checked bit for
- * bit too, not only statistically.  It is the reference's algorithm with six ROUNDING liberties, none of which changes which
+ * bit too, not only statistically.  It is the reference's algorithm with seven ROUNDING liberties, none of which changes which
  * operations are done on which data:
  *   (1) the per-tap perspective divide is one reciprocal and two multiplies, u = X * rcp(Z), v = Y * rcp(Z), where rcp is the
  *       GPU's v_rcp_f32 (1 ulp) — a hardware function, so the oracle evaluates it from a table of its 2^23 mantissa results that the
@@ -76,6 +76,10 @@
  *       d3 = t11 - t10 - t01 + t00 (bilinear_qd): the reference's top-row interpolation as it stands, and "bottom row minus top row"
  *       formed as ONE fused multiply-add on the differences where the reference interpolates the bottom row and subtracts
  *       (gipuma's tex2D blend: three roundings there, one here).  Three FMAs per tap.
+ *   (7) the tap position as m[1] y + (m[0] x + m[2]), two fused operations per coordinate with the inner one shared by a window
+ *       line, where getCorrespondingPoint_cu's matvecmul4noz (config.h:150-162) adds the constant LAST, (m[0] x + m[1] y) + m[2].
+ *       (Rounds 1-5 evaluated the strict mode this way too — a reassociation nobody had stated; the second, independent restatement
+ *       of the cost, tests/test_oracle_independent_sweep.py, found it at the end of round 5 and strict mode now keeps the text's.)
  * The strict mode (no flag) remains the restatement of the reference; this mode is pinned to it only through the tolerances
  * stated in tests/test_gpu_fast_mode.py. */
 #define ORC_FLAG_FAST_ARITH (1u << 7)
@@ -415,11 +419,13 @@ static float pm_cost(const orc_state *s, int view, int x, int y, const float *n4
     float sum_ref = 0, sum_ref_ref = 0, sum_src = 0, sum_src_src = 0, sum_ref_src = 0, wsum = 0;
     for (int i = -s->hrad; i < s->hrad + 1; i += 2) {
         float xi = (float)(x + i);
-        float bx = fmaf(H[0], xi, H[2]), by = fmaf(H[3], xi, H[5]), bz = fmaf(H[6], xi, H[8]);
+        /* getCorrespondingPoint_cu gipuma.cu:161-171 = matvecmul4noz (config.h:150-162): (m[0] x + m[1] y) + m[2], the constant LAST
+         * (S4: mul, fma, add); the x products are the same for a window column */
+        float mx = H[0] * xi, my = H[3] * xi, mz = H[6] * xi;
         for (int j = -s->vrad; j < s->vrad + 1; j += 2) {
             float yj = (float)(y + j);
             float ref_pix = texel(l, w, h, x + i, y + j);
-            float X = fmaf(H[1], yj, bx), Y = fmaf(H[4], yj, by), Z = fmaf(H[7], yj, bz);
+            float X = fmaf(H[1], yj, mx) + H[2], Y = fmaf(H[4], yj, my) + H[5], Z = fmaf(H[7], yj, mz) + H[8];
             float src_pix = bilinear_q(r, w, h, X / Z, Y / Z, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
             float sd = sqrtf((float)(i * i + j * j));
             float cd = fabsf(ref_pix - cen);
@@ -824,8 +830,9 @@ static float rl_cost(const orc_state *s, int view, int x, int y, const float *n4
     V[7] = -(H[0] * H[7] - H[1] * H[6]) / det;
     V[8] = (H[0] * H[4] - H[1] * H[3]) / det;
     float xf = (float)x, yf = (float)y;
-    float Zc = fmaf(H[7], yf, fmaf(H[6], xf, H[8]));
-    float pcx = fmaf(H[1], yf, fmaf(H[0], xf, H[2])) / Zc, pcy = fmaf(H[4], yf, fmaf(H[3], xf, H[5])) / Zc;
+    /* getCorrespondingPoint_cu :161-171 (matvecmul4noz: the two products first, the constant last; S4: mul, fma, add) */
+    float Zc = fmaf(H[7], yf, H[6] * xf) + H[8];
+    float pcx = (fmaf(H[1], yf, H[0] * xf) + H[2]) / Zc, pcy = (fmaf(H[4], yf, H[3] * xf) + H[5]) / Zc;
     float cen = bilinear_q(r, w, h, pcx, pcy, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);
     float sum_ref = 0, sum_ref_ref = 0, sum_src = 0, sum_src_src = 0, sum_ref_src = 0, wsum = 0;
     for (int i = -s->hrad; i < s->hrad + 1; i += 2)
@@ -835,8 +842,8 @@ static float rl_cost(const orc_state *s, int view, int x, int y, const float *n4
             int plx = (int)fx_, ply = (int)fy_;
             float ref_pix = texel(r, w, h, plx, ply);
             float qx = (float)plx, qy = (float)ply;
-            float Z = fmaf(V[7], qy, fmaf(V[6], qx, V[8]));
-            float X = fmaf(V[1], qy, fmaf(V[0], qx, V[2])), Y = fmaf(V[4], qy, fmaf(V[3], qx, V[5]));
+            float Z = fmaf(V[7], qy, V[6] * qx) + V[8];
+            float X = fmaf(V[1], qy, V[0] * qx) + V[2], Y = fmaf(V[4], qy, V[3] * qx) + V[5];
             float u_ = X / Z, v_ = Y / Z;
             if (s->flags & ORC_FLAG_FAST_ARITH) { const float rz = rcp_gpu(s, Z); u_ = X * rz; v_ = Y * rz; }   /* S7 (1): the one liberty lrdiff takes */
             float src_pix = bilinear_q(l, w, h, u_, v_, (s->flags & ORC_FLAG_TEX_FILTER_8BIT) != 0);

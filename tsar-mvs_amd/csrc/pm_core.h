@@ -151,11 +151,15 @@ DEVFN float view_cost_generic(const DevScene* __restrict__ sc, const DevView& vw
 #pragma unroll 1
     for (int i = -hr; i <= hr; i += 2) {
         const float xi = (float)(x + i);
-        const float bx = fma_(H[0], xi, H[2]), by = fma_(H[3], xi, H[5]), bz = fma_(H[6], xi, H[8]);
+        // getCorrespondingPoint_cu gipuma.cu:161-171 (matvecmul4noz, config.h:150-162): (m[0] x + m[1] y) + m[2] — strict mode keeps the
+        // text's association, the constant added LAST (oracle S4: mul, fma, add); the fast arithmetic folds it into the column term
+        // (oracle S7 (7): two fused operations per coordinate)
+        const float bx = STRICT ? H[0] * xi : fma_(H[0], xi, H[2]), by = STRICT ? H[3] * xi : fma_(H[3], xi, H[5]), bz = STRICT ? H[6] * xi : fma_(H[6], xi, H[8]);
 #pragma unroll
         for (int j = -vr; j <= vr; j += 2) {
             const float yj = (float)(y + j);
-            const float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
+            float X = fma_(H[1], yj, bx), Y = fma_(H[4], yj, by), Z = fma_(H[7], yj, bz);
+            if (STRICT) { X += H[2]; Y += H[5]; Z += H[8]; }
             float u, v;
             if (STRICT) {
                 persp_divide_exact<true>(X, Y, Z, u, v);         // = X / Z, Y / Z bit for bit (tsar_device_math.h)

@@ -177,7 +177,8 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
 #pragma unroll
         for (int jj = 0; jj < CH; jj++) {                   // phase 1: tap positions -> byte offsets; phase 2: gathers
             const float yj = ROW ? yj0 + (float)(2 * jj) : fa + (float)(2 * min(c0 + jj, rt) - rt);
-            const float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
+            float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
+            if (STRICT) { X += H[2]; Y += H[5]; Z += H[8]; }      // strict: (m[0] x + m[1] y) + m[2], the constant last (pm_core.h view_cost_generic)
             float u, v;
             int iu, iv;
             if (STRICT) {                                   // the oracle's operations: IEEE divides, min/max clamp, floor / subtract
@@ -274,7 +275,8 @@ DEVFN float view_cost_lut(const DevScene* __restrict__ sc, const DevView& vw, co
         for (int l = 0; l <= rl; l++) {
             const int ol = 2 * l - rl;
             const float xi = fl + (float)ol;
-            const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
+            const float bx = STRICT ? H[0] * xi : fma_(H[ROW ? 1 : 0], xi, H[2]), by = STRICT ? H[3] * xi : fma_(H[ROW ? 4 : 3], xi, H[5]),
+                        bz = STRICT ? H[6] * xi : fma_(H[ROW ? 7 : 6], xi, H[8]);
             const unsigned short* trow = tile + own + (ROW ? ol * tw - rt : ol - rt * tw);
 #pragma unroll 1
             for (int c0 = 0; c0 <= rt; c0 += CH) {

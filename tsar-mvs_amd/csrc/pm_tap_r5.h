@@ -133,7 +133,10 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
         constexpr bool UNR = decltype(unr_tag)::value;
         static_assert(!UNR || (ROW && D16), "the unrolled form is written for the row-wise walk with D16 window loads");
         const float xi = (float)((ROW ? y : x) + i);
-        const float bx = fma_(H[ROW ? 1 : 0], xi, H[2]), by = fma_(H[ROW ? 4 : 3], xi, H[5]), bz = fma_(H[ROW ? 7 : 6], xi, H[8]);
+        // strict mode: the text's association (m[0] x + m[1] y) + m[2] of getCorrespondingPoint_cu (gipuma.cu:161-171, config.h:150-162),
+        // the constant added last (pm_core.h view_cost_generic); fast: folded into the line term (oracle S7 (7))
+        const float bx = STRICT ? H[0] * xi : fma_(H[ROW ? 1 : 0], xi, H[2]), by = STRICT ? H[3] * xi : fma_(H[ROW ? 4 : 3], xi, H[5]),
+                    bz = STRICT ? H[6] * xi : fma_(H[ROW ? 7 : 6], xi, H[8]);
         const int line = (i + 5) >> 1;                // 0..5: which column (or row) this is
         float rcol[6];
         f32x2 wcol[3];
@@ -164,7 +167,8 @@ DEVFN float view_cost_r5(const DevScene* __restrict__ sc, const DevView& vw, con
 #pragma unroll
         for (int jj = 0; jj < 6; jj++) {                        // phase 1: tap positions -> element index; phase 2: gathers
             const float yj = (float)((ROW ? x : y) + 2 * jj - 5);
-            const float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
+            float X = fma_(H[ROW ? 0 : 1], yj, bx), Y = fma_(H[ROW ? 3 : 4], yj, by), Z = fma_(H[ROW ? 6 : 7], yj, bz);
+            if (STRICT) { X += H[2]; Y += H[5]; Z += H[8]; }
             float u, v;
             // Clamp range.  The oracle clamps to [-1, w] (tex2D at u + .5 with clamp addressing).  The offset is unsigned from entry
             // (1, 1), so floor(u) must be >= 0: clamp to [0, w - 1] instead.  The sample is the same bit for bit: for u in [-1, 0)

@@ -23,8 +23,9 @@ DEVFN float reverse_cost(const DevScene* __restrict__ sc, const DevView& vw, int
     V[7] = -(H[0] * H[7] - H[1] * H[6]) / det;
     V[8] = (H[0] * H[4] - H[1] * H[3]) / det;
     const float xf = (float)x, yf = (float)y;
-    const float Zc = fma_(H[7], yf, fma_(H[6], xf, H[8]));
-    const float pcx = fma_(H[1], yf, fma_(H[0], xf, H[2])) / Zc, pcy = fma_(H[4], yf, fma_(H[3], xf, H[5])) / Zc;
+    // getCorrespondingPoint_cu gipuma.cu:161-171 (matvecmul4noz: the two products first, the constant last; oracle S4: mul, fma, add)
+    const float Zc = fma_(H[7], yf, H[6] * xf) + H[8];
+    const float pcx = (fma_(H[1], yf, H[0] * xf) + H[2]) / Zc, pcy = (fma_(H[4], yf, H[3] * xf) + H[5]) / Zc;
     const bool q8 = (sc->flags & TSAR_FLAG_TEX_FILTER_8BIT) != 0;
     const float cen = sample_bilinear<QUAD>(vw, w, h, qp, pcx, pcy, q8);
     float sum_ref = 0.f, sum_ref_ref = 0.f, sum_src = 0.f, sum_src_src = 0.f, sum_ref_src = 0.f, wsum = 0.f;
@@ -35,8 +36,8 @@ DEVFN float reverse_cost(const DevScene* __restrict__ sc, const DevView& vw, int
             const int plx = (int)fx_, ply = (int)fy_;
             const float ref_pix = vw.img[(size_t)min(max(ply, 0), h - 1) * w + min(max(plx, 0), w - 1)];
             const float qx = (float)plx, qy = (float)ply;
-            const float Z = fma_(V[7], qy, fma_(V[6], qx, V[8]));
-            const float X = fma_(V[1], qy, fma_(V[0], qx, V[2])), Y = fma_(V[4], qy, fma_(V[3], qx, V[5]));
+            const float Z = fma_(V[7], qy, V[6] * qx) + V[8];
+            const float X = fma_(V[1], qy, V[0] * qx) + V[2], Y = fma_(V[4], qy, V[3] * qx) + V[5];
             float u, v;
             if (STRICT) persp_divide_exact<true>(X, Y, Z, u, v);   // = X / Z, Y / Z bit for bit
             else { const float rz = __builtin_amdgcn_rcpf(Z); u = X * rz; v = Y * rz; }
