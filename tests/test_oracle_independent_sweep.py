@@ -520,3 +520,74 @@ def test_matching_cost_operation_for_operation(box, n_best):
             if want[1] >= 0:
                 assert f32(rt) == want[2]
     assert hit_valid > 100
+
+
+def rl_cost_f32(orc, img_ptrs, view, x, y, n4, hrad, vrad):
+    """rlCost, gipuma.cu:300-392: `r` is the source image, `l` the reference image; same shared primitives as pm_cost_f32"""
+    import ctypes as C
+    L = orc.L
+    H = orc.homography(view, n4).reshape(-1)
+    w, h = orc.w, orc.h
+    src = orc.images[view]
+    tex = lambda v, u_, v_: f32(L.orc_bilinear(img_ptrs[v], w, h, C.c_float(u_), C.c_float(v_)))
+    det = H[0] * H[4] * H[8] + H[1] * H[5] * H[6] + H[2] * H[3] * H[7] - H[2] * H[4] * H[6] - H[1] * H[3] * H[8] - H[0] * H[5] * H[7]
+    V = [H[4] * H[8] - H[5] * H[7], H[1] * H[8] - H[2] * H[7], H[1] * H[5] - H[2] * H[4],
+         H[3] * H[8] - H[5] * H[6], H[0] * H[8] - H[2] * H[6], H[0] * H[5] - H[2] * H[3],
+         H[3] * H[7] - H[4] * H[6], H[0] * H[7] - H[1] * H[6], H[0] * H[4] - H[1] * H[3]]
+    V = [V[0] / det, -V[1] / det, V[2] / det, -V[3] / det, V[4] / det, -V[5] / det, V[6] / det, -V[7] / det, V[8] / det]
+    pcx, pcy = _warp(H, x, y)
+    cen = tex(view, pcx, pcy)
+    s_r = s_rr = s_s = s_ss = s_rs = wsum = f32(0)
+    for i in range(-hrad, hrad + 1, 2):
+        for j in range(-vrad, vrad + 1, 2):
+            plx, ply = int(np.trunc(pcx + f32(i))), int(np.trunc(pcy + f32(j)))       # make_int2(pt_c.x + i, pt_c.y + j): toward zero
+            r = src[min(max(ply, 0), h - 1), min(max(plx, 0), w - 1)]
+            u_, v_ = _warp(V, plx, ply)
+            s = tex(0, u_, v_)
+            sd = np.sqrt(f32(i * i + j * j))
+            cd = abs(r - cen)
+            wt = f32(L.orc_expf(C.c_float(-sd / (f32(2) * f32(5) * f32(5)) - cd / (f32(2) * f32(3) * f32(3)))))
+            s_r = s_r + wt * r
+            s_rr = s_rr + wt * r * r
+            s_s = s_s + wt * s
+            s_ss = s_ss + wt * s * s
+            s_rs = s_rs + wt * r * s
+            wsum = wsum + wt
+    inv = f32(1) / wsum
+    s_r, s_rr, s_s, s_ss, s_rs = s_r * inv, s_rr * inv, s_s * inv, s_ss * inv, s_rs * inv
+    var_r = s_rr - s_r * s_r
+    var_s = s_ss - s_s * s_s
+    if var_r < f32(1e-5) or var_s < f32(1e-5):
+        return f32(2)
+    covar = s_rs - s_r * s_s
+    return max(f32(0), min(f32(2), f32(1) - covar / np.sqrt(var_r * var_s)))
+
+
+def test_lrdiff_operation_for_operation():
+    """gipuma_getlrdiff :1160-1186 over rlCost, and gipuma_getview :1188-1213, after an iteration: every pixel, bit for bit"""
+    import ctypes as C
+    sc, orc = _scene_and_oracle(nofma=True, w=44, h=32, views=4, box=7, n_best=1)
+    ptrs = [im.ctypes.data_as(C.c_void_p) for im in orc.images]
+    orc.L.orc_bilinear.restype = C.c_float
+    orc.L.orc_expf.restype = C.c_float
+    cam = _Cam(orc.camera(0))
+    orc.pm_init()
+    orc.pm_iterate(1)
+    planes, cost, bv = orc.norm4.copy(), orc.c.copy(), orc.beview.copy()
+    orc.lrdiff_op()
+    orc.getview()
+    checked = 0
+    for y in range(orc.h):
+        for x in range(orc.w):
+            if not (1 <= bv[y, x] <= 4):
+                continue                                                    # (no accepted hypothesis yet: the build leaves lrdiff as it is)
+            rc = rl_cost_f32(orc, ptrs, int(bv[y, x]), x, y, planes[y, x], 3, 3)
+            d = abs(cost[y, x] - rc)
+            d = f32(1) if d > f32(1) else d
+            assert np.array([d], np.float32).view(np.uint32)[0] == orc.lrdiff[y, x:x + 1].view(np.uint32)[0], (x, y, d, orc.lrdiff[y, x])
+            conf = ((f32(2) - cost[y, x]) / f32(2) + (f32(1) - d)) / f32(2)
+            assert conf == orc.confid[y, x]
+            depth = cam.f * cam.baseline / _depth_of_plane(cam, planes[y, x], x, y)
+            assert depth == orc.depth[y, x]
+            checked += 1
+    assert checked > 0.8 * orc.h * orc.w
