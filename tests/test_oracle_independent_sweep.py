@@ -591,3 +591,46 @@ def test_lrdiff_operation_for_operation():
             assert depth == orc.depth[y, x]
             checked += 1
     assert checked > 0.8 * orc.h * orc.w
+
+
+def test_compute_disp_final_operation_for_operation():
+    """gipuma_compute_disp_final gipuma.cu:757-808: the multi-scale merge (take the coarser level's plane where the disparities differ by more
+    than 6 on textured regions, or always on regions flagged -1), the clamp of the plane into the depth range, the output conversion"""
+    sc, orc = _scene_and_oracle(nofma=True, w=36, h=26)
+    cv = orc.camera(0)
+    cam = _Cam(cv)
+    RorigInv = np.array(list(cv.RorigInv), np.float32)
+    rows, cols = orc.h, orc.w
+    orc.pm_init()
+    orc.pm_iterate(1)
+    planes, cost = orc.norm4.copy(), orc.c.copy()
+    cost[2, 3] = 2.0
+    orc.c[2, 3] = 2.0
+    rng = np.random.default_rng(12)
+    resize4 = planes[rng.integers(0, rows, (rows, cols)), rng.integers(0, cols, (rows, cols))].copy()      # foreign planes: many out of range here
+    resize4[::3] = planes[::3] * np.float32(1.0002)                                                          # and near copies
+    text = rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), (rows, cols))
+    out = orc.compute_disp_final(resize4, text)
+    fb = cam.f * cam.baseline
+    taken = clamped = 0
+    for y in range(rows):
+        for x in range(cols):
+            n4 = planes[y, x].copy()
+            disp_now = fb / _depth_of_plane(cam, n4, x, y)
+            disp_org = fb / _depth_of_plane(cam, resize4[y, x], x, y)
+            if (abs(disp_now - disp_org) > f32(6) and text[y, x] == 1) or text[y, x] == -1:
+                n4 = resize4[y, x].copy()
+                taken += 1
+            disp = _depth_of_plane(cam, n4, x, y)
+            if disp > cam.depthMax:
+                n4[3] = _plane_offset(cam, n4, x, y, cam.depthMax)
+                clamped += 1
+            if disp < cam.depthMin:
+                n4[3] = _plane_offset(cam, n4, x, y, cam.depthMin)
+                clamped += 1
+            depth = _depth_of_plane(cam, n4, x, y)
+            o = _matvec(RorigInv, n4)
+            want = np.array([o[0], o[1], o[2], depth if cost[y, x] != f32(2) else f32(0)], np.float32)
+            assert np.array_equal(want.view(np.uint32), out[y, x].view(np.uint32)), (x, y, want, out[y, x])
+            assert np.array([depth], np.float32).view(np.uint32)[0] == orc.depth[y, x:x + 1].view(np.uint32)[0]
+    assert taken > 100 and clamped > 20
