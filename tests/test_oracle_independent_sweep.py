@@ -634,3 +634,141 @@ def test_compute_disp_final_operation_for_operation():
             assert np.array_equal(want.view(np.uint32), out[y, x].view(np.uint32)), (x, y, want, out[y, x])
             assert np.array([depth], np.float32).view(np.uint32)[0] == orc.depth[y, x:x + 1].view(np.uint32)[0]
     assert taken > 100 and clamped > 20
+
+
+# ---- row A13: the weighted median filters, from the text ----
+
+def _bubble(vals, *carried):
+    """the reference's sort, gipuma.cu:1564-1611 / :1369-1416, on ONE of its four lists: `num` outer passes whose inner loop reaches index
+    num (the zero-initialised slot behind the list takes part); strict `>`; the carried arrays swap with the values"""
+    num = len(vals) - 1
+    for i in range(num):
+        for j in range(num - i):
+            if vals[j] > vals[j + 1]:
+                vals[j], vals[j + 1] = vals[j + 1], vals[j]
+                for c in carried:
+                    c[j], c[j + 1] = c[j + 1], c[j]
+
+
+def _stable(vals, *carried):
+    """the same order without the quadratic loop: a strict-`>` bubble sort is a stable sort (asserted against _bubble on a sample)"""
+    order = sorted(range(len(vals)), key=lambda k: vals[k])
+    out = [[vals[k] for k in order]] + [[c[k] for k in order] for c in carried]
+    return out
+
+
+def _wmf_pixel(orc, L, cam, scale_in, depth_in, n_in, x, y, radius, gap, sdiv, literal):
+    """taps, sort, weighted medians and the plane through the median-depth pixel of gipuma_WMF :1538-1676 / gipuma_WMF_Final :1333-1473.
+    Returns (num, norm_mid or None)."""
+    import ctypes as C
+    rows, cols = orc.h, orc.w
+    img = orc.images[0]
+    w_, d_, n_, x_, y_, z_ = [], [], [], [], [], []
+    for i in range(-radius, radius + 1, gap):
+        for j in range(-radius, radius + 1, gap):
+            px, py = x + i, y + j
+            if 0 <= px < cols and 0 <= py < rows and scale_in[py, px] == 1:
+                cen, refp = img[y, x], img[py, px]
+                color_dist = abs(refp - cen)
+                spatial_dist = np.sqrt(f32(i * i + j * j)) / f32(sdiv)
+                wt = f32(L.orc_expf(C.c_float(-spatial_dist / (f32(2) * f32(2))))) * f32(L.orc_expf(C.c_float(-color_dist / (f32(3) * f32(3)))))
+                w_.append(wt); d_.append(depth_in[py, px]); n_.append(py * cols + px)
+                x_.append(n_in[py, px, 0]); y_.append(n_in[py, px, 1]); z_.append(n_in[py, px, 2])
+    num = len(w_)
+    if num == 0:
+        return 0, None
+    z0 = f32(0)
+    lists = [(d_ + [z0], w_ + [z0], n_ + [0]), (x_ + [z0], list(w_) + [z0]), (y_ + [z0], list(w_) + [z0]), (z_ + [z0], list(w_) + [z0])]
+    if literal:
+        for l in lists:
+            _bubble(*l)
+        (d, w, n), (xs, w1), (ys, w2), (zs, w3) = lists
+    else:
+        (d, w, n), (xs, w1), (ys, w2), (zs, w3) = [_stable(*l) for l in lists]
+    wSum = f32(0)
+    for i in range(num):
+        wSum = wSum + w[i]
+    half = wSum / f32(2)
+
+    def median(vals, wts):
+        acc = f32(0)
+        for i in range(num):
+            acc = acc + wts[i]
+            if acc >= half:
+                return vals[i]
+        return vals[num - 1]          # (the reference leaves norm_mid uninitialised here; the build defines the last sorted element)
+    nm = [median(xs, w1), median(ys, w2), median(zs, w3)]
+    acc = f32(0)
+    for i in range(num):
+        acc = acc + w[i]
+        if acc >= half:
+            weimid = n[i]
+            disp_mid = cam.f * cam.baseline / depth_in.reshape(-1)[weimid]
+            nrm = np.float64(np.sqrt(nm[0] * nm[0] + nm[1] * nm[1] + nm[2] * nm[2]))       # `double xyzsqr = sqrtf(...)`
+            nm = [f32(np.float64(nm[0]) / nrm), f32(np.float64(nm[1]) / nrm), f32(np.float64(nm[2]) / nrm)]
+            return num, np.array([nm[0], nm[1], nm[2], _plane_offset(cam, nm, weimid % cols, weimid // cols, disp_mid)], np.float32)
+    return num, None
+
+
+def test_weighted_median_filters_from_the_text(small_scene):
+    import ctypes as C
+    sc = small_scene                                      # 96 x 64, 3 source views
+    images = [im.numpy() for im in sc.images]
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=5, box=7, n_best=1, nofma=True)
+    L = orc.L
+    L.orc_expf.restype = C.c_float
+    cam = _Cam(orc.camera(0))
+    rows, cols = orc.h, orc.w
+    fb = cam.f * cam.baseline
+    orc.pm_init()
+    orc.pm_iterate(2)
+    orc.getview()                                         # lines->depth = f b / depth of the plane
+    rng = np.random.default_rng(21)
+    orc.scale[...] = (rng.random((rows, cols)) < 0.85).astype(np.float32)
+    sample = {(int(a), int(b)) for a, b in zip(rng.integers(0, cols, 12), rng.integers(0, rows, 12))}
+    # ---- gipuma_WMF :1499-1698, the last two of its four passes (tap grids of radius 20 and 10)
+    for it in (2, 3):
+        po, repo = 2 ** it, 2 ** (3 - it)
+        radius, gap, ths = 80 // po, 16 // po, 24 // po
+        scale_in, depth_in, n_in = orc.scale.copy(), orc.depth.copy(), orc.norm4.copy()
+        orc.wmf_detect(it)
+        flagged = 0
+        for y in range(rows):
+            for x in range(cols):
+                num, nm = _wmf_pixel(orc, L, cam, scale_in, depth_in, n_in, x, y, radius, gap, repo, literal=False)
+                if (x, y) in sample:
+                    num2, nm2 = _wmf_pixel(orc, L, cam, scale_in, depth_in, n_in, x, y, radius, gap, repo, literal=True)
+                    assert num2 == num and (nm is None) == (nm2 is None) and (nm is None or np.array_equal(nm.view(np.uint32), nm2.view(np.uint32)))
+                want = f32(0)
+                if num > 0 and nm is not None:
+                    disp_now = fb / _depth_of_plane(cam, nm, x, y)
+                    disp_org = fb / _depth_of_plane(cam, n_in[y, x], x, y)
+                    want = f32(0) if abs(disp_now - disp_org) > f32(ths) else f32(1)       # DEPTH_THS_MIN / MAX are 0 (:38-39): never true
+                assert orc.scale[y, x] == want, (it, x, y, num, want)
+                flagged += want == 0
+        assert 0 < flagged < rows * cols
+    # ---- gipuma_WMF_Final :1294-1497: unreliable pixels of textured regions are refilled where enough reliable taps surround them
+    orc.set_regions(np.zeros((rows, cols), np.int32), np.array([1.0], np.float32))
+    filled = 0
+    for it in (0, 1):
+        po = 2 ** it
+        radius, gap, ths = 5 * po, po, 32 // po
+        scale_in, depth_in, n_in = orc.scale.copy(), orc.depth.copy(), orc.norm4.copy()
+        orc.wmf_fill(it)
+        for y in range(rows):
+            for x in range(cols):
+                if scale_in[y, x] != 0:
+                    assert np.array_equal(orc.norm4[y, x].view(np.uint32), n_in[y, x].view(np.uint32)) and orc.scale[y, x] == scale_in[y, x]
+                    continue
+                num, nm = _wmf_pixel(orc, L, cam, scale_in, depth_in, n_in, x, y, radius, gap, po, literal=False)
+                if num < ths or nm is None:
+                    assert np.array_equal(orc.norm4[y, x].view(np.uint32), n_in[y, x].view(np.uint32)) and orc.scale[y, x] == 0, (it, x, y, num)
+                    continue
+                assert np.array_equal(orc.norm4[y, x].view(np.uint32), nm.view(np.uint32)), (it, x, y)
+                disp = fb / _depth_of_plane(cam, nm, x, y)
+                if disp <= f32(orc.min_disp) or disp >= f32(orc.max_disp):
+                    assert orc.scale[y, x] == 0 and orc.depth[y, x] == f32(orc.min_disp)
+                else:
+                    assert orc.scale[y, x] == 1 and orc.depth[y, x] == disp
+                    filled += 1
+    assert filled > 10
