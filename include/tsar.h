@@ -96,8 +96,11 @@ extern "C" {
                                                   (reference seeds with c[up_far], gipuma.cu:906) */
 #define TSAR_FLAG_FIX_RIGHT_FAR_CMP  (1u << 1) /* right_far arm picks the minimum
                                                   (reference comparison is inverted, gipuma.cu:943) */
-#define TSAR_FLAG_STRICT_DIV         (1u << 2) /* IEEE divisions in the per-tap perspective divide
-                                                  (bit-exact against the CPU oracle; slower) */
+#define TSAR_FLAG_STRICT_DIV         (1u << 2) /* the reference's arithmetic, operation for operation: IEEE divisions in the per-tap
+                                                  perspective divide, the tap position as (m0 x + m1 y) + m2 (getCorrespondingPoint_cu
+                                                  gipuma.cu:161-171), (w r) s, window columns, the reference's homography and blend
+                                                  (bit-exact against the CPU oracle; ~28 % slower than the default arithmetic, whose
+                                                  seven rounding-level liberties oracle/tsar_oracle.c S7 lists) */
 #define TSAR_FLAG_NO_LINE_CLOSING    (1u << 4) /* tsar_detect_weak_texture: skip the Hough boundary closing of large regions
                                                   (main.cpp:385-435; on by default like the reference's HoughLinesP step) */
 
