@@ -16,7 +16,7 @@ cp "$ROOT/oracle/libtsar_oracle.so" "$S/oracle.bak"; cp "$ROOT/tsar-mvs_amd/tsar
 touch "$ROOT/oracle/libtsar_oracle.so"
 cd "$ROOT"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 OMP_NUM_THREADS=4 \
-    python -m pytest tests/test_oracle_known_answers.py tests/test_slic_reference_golden.py tests/test_oracle_independent_float64.py tests/test_golden.py -x -q -m "not gpu"
+    python -m pytest tests/test_oracle_known_answers.py tests/test_slic_reference_golden.py tests/test_oracle_independent_float64.py tests/test_oracle_independent_sweep.py tests/test_golden.py -x -q -m "not gpu"
 cp "$S/oracle.bak" "$ROOT/oracle/libtsar_oracle.so"; touch "$ROOT/oracle/libtsar_oracle.so"
 (cd "$ROOT/tsar-mvs_amd" && g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -pthread -o tsar_gipuma host/tsar_gipuma.cpp -L. -ltsar_hip -lz -Wl,-rpath,"$ROOT/tsar-mvs_amd")
 ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_io_cli.py tests/test_jpeg_decode.py -q -m "not gpu"
