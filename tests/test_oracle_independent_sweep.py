@@ -16,7 +16,14 @@ build's replacement of clock-seeded cuRAND), reads from the launch-start state (
 Every expression below is one IEEE operation per operator in the reference's order (numpy float32 scalars), which is what the oracle
 computes when built with -DORC_NO_FMA (every fmaf of its S4 written as multiply-then-add): against that build the restatement must agree
 BIT FOR BIT; against the default build (S4's fused operations) to rounding.  A misreading of the text would have to be made twice, in two
-languages and two loop structures, to go unseen."""
+languages and two loop structures, to go unseen.
+
+Further down, the same way: rows A10 / A12 (get_disp, compute_disp, compute_disp_final, dptow, update_scale, update_scale_2), the matching
+cost itself operation for operation (getCorrespondingPoint_cu :161-171, pmCost :229-298, pmCostMultiview_cu :455-518 with sort_small,
+rlCost :300-392, gipuma_getlrdiff :1160-1186, gipuma_getview :1188-1213) and row A13 (gipuma_WMF :1499-1698, gipuma_WMF_Final :1294-1497).
+What it found when it was written (end of round 5): the oracle and the kernels evaluated a tap's position as m[1] y + (m[0] x + m[2]) — the
+line term hoisted with the constant folded in — where matvecmul4noz (config.h:150-162) forms (m[0] x + m[1] y) + m[2]; strict mode follows
+the text since, and test_matching_cost_operation_for_operation fails on the first pixel if it does not."""
 import numpy as np
 import pytest
 
