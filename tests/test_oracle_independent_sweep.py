@@ -779,3 +779,109 @@ def test_weighted_median_filters_from_the_text(small_scene):
                     assert orc.scale[y, x] == 1 and orc.depth[y, x] == disp
                     filled += 1
     assert filled > 10
+
+
+# ---- the default ("fast") arithmetic: the reference's text with the seven liberties of oracle S7 applied, and nothing else ----
+
+def _rcp_table_correctly_rounded():
+    """a stand-in for the device's v_rcp_f32 table (the GPU tests read the real one): the correctly rounded reciprocal of every
+    mantissa of [1, 2) — any table serves a CPU test of WHERE the reciprocal enters"""
+    m = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+    return (np.float32(1) / m).astype(np.float32)
+
+
+def _rcp(table, x):                                      # S7 (1): table on the mantissa, exponent and sign exact
+    bits = np.array([x], np.float32).view(np.uint32)[0]
+    e, m = int((bits >> 23) & 0xFF), int(bits & 0x7FFFFF)
+    r = np.array([table[m]], np.float32).view(np.uint32)[0]
+    re = int((r >> 23) & 0xFF) + 127 - e
+    assert 0 < re < 255 and 0 < e < 255
+    out = (int(bits) & 0x80000000) | (re << 23) | (int(r) & 0x7FFFFF)
+    return np.array([out], np.uint32).view(np.float32)[0]
+
+
+def _bilinear_differences(img, u, v):
+    """S7 (4) + (6): clamp to the image (the same sample as tex2D's clamp addressing), the blend (t00 + ax d1) + ay (d2 + ax d3)"""
+    h, w = img.shape
+    u = min(max(u, f32(-1)), f32(w))
+    v = min(max(v, f32(-1)), f32(h))
+    fu, fv = np.floor(u), np.floor(v)
+    ax, ay = u - fu, v - fv
+    x0, y0 = int(fu), int(fv)
+    t = lambda xx, yy: img[min(max(yy, 0), h - 1), min(max(xx, 0), w - 1)]
+    t00, t10, t01, t11 = t(x0, y0), t(x0 + 1, y0), t(x0, y0 + 1), t(x0 + 1, y0 + 1)
+    d1, d2 = t10 - t00, t01 - t00
+    d3 = (t11 - t01) - d1
+    return ay * (ax * d3 + d2) + (ax * d1 + t00)
+
+
+def pm_cost_fast_f32(orc, cv0, cvv, table, view, x, y, n4, hrad, vrad):
+    """pm_cost_f32 above with the seven liberties of oracle S7 and nothing else changed"""
+    import ctypes as C
+    L = orc.L
+    w, h = orc.w, orc.h
+    ref, src = orc.images[0], orc.images[view]
+    Kinv = np.array(list(cv0.Kinv), np.float32)
+    A, b = np.array(list(cvv.A), np.float32), np.array(list(cvv.b), np.float32)
+    inv_d = _rcp(table, n4[3])                                                        # (2): H = A - b m^T, m = K_ref^-T n * rcp(d)
+    m = [((n4[0] * Kinv[c] + n4[1] * Kinv[3 + c]) + n4[2] * Kinv[6 + c]) * inv_d for c in range(3)]
+    H = [(-b[r]) * m[c] + A[3 * r + c] for r in range(3) for c in range(3)]
+    cen = ref[y, x]
+    s_r = s_rr = wsum = f32(0)
+    wts = {}
+    for i in range(-hrad, hrad + 1, 2):                                               # the reference terms: the text's order
+        for j in range(-vrad, vrad + 1, 2):
+            r = ref[min(max(y + j, 0), h - 1), min(max(x + i, 0), w - 1)]
+            sd = np.sqrt(f32(i * i + j * j))
+            wt = f32(L.orc_expf(C.c_float(-sd / (f32(2) * f32(5) * f32(5)) - abs(r - cen) / (f32(2) * f32(3) * f32(3)))))
+            wts[(i, j)] = (wt, r)
+            s_r = s_r + wt * r
+            s_rr = s_rr + wt * r * r
+            wsum = wsum + wt
+    s_s = s_ss = s_rs = f32(0)
+    for j in range(-vrad, vrad + 1, 2):                                               # (5): the source sums row by row
+        yj = f32(y + j)
+        bx, by, bz = H[1] * yj + H[2], H[4] * yj + H[5], H[7] * yj + H[8]            # (7): the line term with the constant folded in
+        for i in range(-hrad, hrad + 1, 2):
+            xi = f32(x + i)
+            X, Y, Z = H[0] * xi + bx, H[3] * xi + by, H[6] * xi + bz
+            rz = _rcp(table, Z)                                                       # (1)
+            s = _bilinear_differences(src, X * rz, Y * rz)                            # (4), (6)
+            wt, r = wts[(i, j)]
+            ws = wt * s
+            s_s = s_s + ws
+            s_ss = s_ss + ws * s
+            s_rs = s_rs + ws * r                                                      # (3): (w s) r
+    inv = f32(1) / wsum
+    s_r, s_rr, s_s, s_ss, s_rs = s_r * inv, s_rr * inv, s_s * inv, s_ss * inv, s_rs * inv
+    var_r = s_rr - s_r * s_r
+    var_s = s_ss - s_s * s_s
+    if var_r < f32(1e-5) or var_s < f32(1e-5):
+        return f32(2)
+    return max(f32(0), min(f32(2), f32(1) - (s_rs - s_r * s_s) / np.sqrt(var_r * var_s)))
+
+
+def test_fast_arithmetic_is_the_text_plus_its_seven_liberties():
+    """oracle S7 says the default arithmetic of the library is the reference's algorithm with seven rounding-level liberties.  Here the
+    float32 restatement of the text takes exactly those seven and must then equal the oracle's fast cost bit for bit (unfused build,
+    8-bit imagery's row order): the list is complete."""
+    import ctypes as C
+    sc = synth.make_scene(48, 36, 4, seed=5)
+    images = [np.rint(im.cpu().numpy()).astype(np.float32) for im in sc.images]       # 8-bit imagery: exact integer texels
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=77, box=11, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY, nofma=True)
+    table = _rcp_table_correctly_rounded()
+    orc.set_rcp_table(table)
+    orc.L.orc_expf.restype = C.c_float
+    orc.pm_init()
+    orc.pm_iterate(1)
+    planes = orc.norm4.copy()
+    cv0 = orc.camera(0)
+    checked = 0
+    for y in list(range(0, orc.h, 5)) + [orc.h - 1]:
+        for x in list(range(0, orc.w, 7)) + [orc.w - 1]:
+            for v in (1, 2, 3, 4):
+                c = pm_cost_fast_f32(orc, cv0, orc.camera(v), table, v, x, y, planes[y, x], 5, 5)
+                got = f32(orc.pm_cost(v, x, y, planes[y, x]))
+                assert np.array([c], np.float32).view(np.uint32)[0] == np.array([got], np.float32).view(np.uint32)[0], (x, y, v, c, got)
+                checked += c < f32(2)
+    assert checked > 100 and not orc.rcp_out_of_range
