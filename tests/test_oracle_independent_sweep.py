@@ -815,7 +815,7 @@ def _bilinear_differences(img, u, v):
     return ay * (ax * d3 + d2) + (ax * d1 + t00)
 
 
-def pm_cost_fast_f32(orc, cv0, cvv, table, view, x, y, n4, hrad, vrad):
+def pm_cost_fast_f32(orc, cv0, cvv, table, view, x, y, n4, hrad, vrad, rows=True):
     """pm_cost_f32 above with the seven liberties of oracle S7 and nothing else changed"""
     import ctypes as C
     L = orc.L
@@ -839,19 +839,23 @@ def pm_cost_fast_f32(orc, cv0, cvv, table, view, x, y, n4, hrad, vrad):
             s_rr = s_rr + wt * r * r
             wsum = wsum + wt
     s_s = s_ss = s_rs = f32(0)
-    for j in range(-vrad, vrad + 1, 2):                                               # (5): the source sums row by row
-        yj = f32(y + j)
-        bx, by, bz = H[1] * yj + H[2], H[4] * yj + H[5], H[7] * yj + H[8]            # (7): the line term with the constant folded in
-        for i in range(-hrad, hrad + 1, 2):
-            xi = f32(x + i)
-            X, Y, Z = H[0] * xi + bx, H[3] * xi + by, H[6] * xi + bz
-            rz = _rcp(table, Z)                                                       # (1)
-            s = _bilinear_differences(src, X * rz, Y * rz)                            # (4), (6)
-            wt, r = wts[(i, j)]
-            ws = wt * s
-            s_s = s_s + ws
-            s_ss = s_ss + ws * s
-            s_rs = s_rs + ws * r                                                      # (3): (w s) r
+    # (5): on 8-bit imagery the source sums run row by row (x fastest); float imagery keeps the text's columns
+    lines = [(a, b_) for a in range(-(vrad if rows else hrad), (vrad if rows else hrad) + 1, 2) for b_ in range(-(hrad if rows else vrad), (hrad if rows else vrad) + 1, 2)]
+    for a, b_ in lines:
+        i, j = (b_, a) if rows else (a, b_)
+        xi, yj = f32(x + i), f32(y + j)
+        # (7): the line term with the constant folded in, then the coordinate that runs along the line
+        if rows:
+            X, Y, Z = H[0] * xi + (H[1] * yj + H[2]), H[3] * xi + (H[4] * yj + H[5]), H[6] * xi + (H[7] * yj + H[8])
+        else:
+            X, Y, Z = H[1] * yj + (H[0] * xi + H[2]), H[4] * yj + (H[3] * xi + H[5]), H[7] * yj + (H[6] * xi + H[8])
+        rz = _rcp(table, Z)                                                           # (1)
+        s = _bilinear_differences(src, X * rz, Y * rz)                                # (4), (6)
+        wt, r = wts[(i, j)]
+        ws = wt * s
+        s_s = s_s + ws
+        s_ss = s_ss + ws * s
+        s_rs = s_rs + ws * r                                                          # (3): (w s) r
     inv = f32(1) / wsum
     s_r, s_rr, s_s, s_ss, s_rs = s_r * inv, s_rr * inv, s_s * inv, s_ss * inv, s_rs * inv
     var_r = s_rr - s_r * s_r
@@ -861,14 +865,15 @@ def pm_cost_fast_f32(orc, cv0, cvv, table, view, x, y, n4, hrad, vrad):
     return max(f32(0), min(f32(2), f32(1) - (s_rs - s_r * s_s) / np.sqrt(var_r * var_s)))
 
 
-def test_fast_arithmetic_is_the_text_plus_its_seven_liberties():
+@pytest.mark.parametrize("rows", [True, False])
+def test_fast_arithmetic_is_the_text_plus_its_seven_liberties(rows):
     """oracle S7 says the default arithmetic of the library is the reference's algorithm with seven rounding-level liberties.  Here the
     float32 restatement of the text takes exactly those seven and must then equal the oracle's fast cost bit for bit (unfused build,
     8-bit imagery's row order): the list is complete."""
     import ctypes as C
     sc = synth.make_scene(48, 36, 4, seed=5)
     images = [np.rint(im.cpu().numpy()).astype(np.float32) for im in sc.images]       # 8-bit imagery: exact integer texels
-    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=77, box=11, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY, nofma=True)
+    orc = ol.Oracle(images, sc.K, sc.R, sc.t, sc.depth_min, sc.depth_max, seed=77, box=11, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY if rows else ol.FLAG_FAST_ARITH, nofma=True)
     table = _rcp_table_correctly_rounded()
     orc.set_rcp_table(table)
     orc.L.orc_expf.restype = C.c_float
@@ -880,7 +885,7 @@ def test_fast_arithmetic_is_the_text_plus_its_seven_liberties():
     for y in list(range(0, orc.h, 5)) + [orc.h - 1]:
         for x in list(range(0, orc.w, 7)) + [orc.w - 1]:
             for v in (1, 2, 3, 4):
-                c = pm_cost_fast_f32(orc, cv0, orc.camera(v), table, v, x, y, planes[y, x], 5, 5)
+                c = pm_cost_fast_f32(orc, cv0, orc.camera(v), table, v, x, y, planes[y, x], 5, 5, rows=rows)
                 got = f32(orc.pm_cost(v, x, y, planes[y, x]))
                 assert np.array([c], np.float32).view(np.uint32)[0] == np.array([got], np.float32).view(np.uint32)[0], (x, y, v, c, got)
                 checked += c < f32(2)
