@@ -529,7 +529,7 @@ def test_matching_cost_operation_for_operation(box, n_best):
     assert hit_valid > 100
 
 
-def rl_cost_f32(orc, img_ptrs, view, x, y, n4, hrad, vrad):
+def rl_cost_f32(orc, img_ptrs, view, x, y, n4, hrad, vrad, rcp_table=None):
     """rlCost, gipuma.cu:300-392: `r` is the source image, `l` the reference image; same shared primitives as pm_cost_f32"""
     import ctypes as C
     L = orc.L
@@ -550,6 +550,11 @@ def rl_cost_f32(orc, img_ptrs, view, x, y, n4, hrad, vrad):
             plx, ply = int(np.trunc(pcx + f32(i))), int(np.trunc(pcy + f32(j)))       # make_int2(pt_c.x + i, pt_c.y + j): toward zero
             r = src[min(max(ply, 0), h - 1), min(max(plx, 0), w - 1)]
             u_, v_ = _warp(V, plx, ply)
+            if rcp_table is not None:             # the default arithmetic's one liberty here (oracle S7 (1)): the quotient as a product with rcp(Z)
+                Xq = V[0] * f32(plx) + V[1] * f32(ply) + V[2]
+                Yq = V[3] * f32(plx) + V[4] * f32(ply) + V[5]
+                rz = _rcp(rcp_table, V[6] * f32(plx) + V[7] * f32(ply) + V[8])
+                u_, v_ = Xq * rz, Yq * rz
             s = tex(0, u_, v_)
             sd = np.sqrt(f32(i * i + j * j))
             cd = abs(r - cen)
@@ -570,10 +575,16 @@ def rl_cost_f32(orc, img_ptrs, view, x, y, n4, hrad, vrad):
     return max(f32(0), min(f32(2), f32(1) - covar / np.sqrt(var_r * var_s)))
 
 
-def test_lrdiff_operation_for_operation():
-    """gipuma_getlrdiff :1160-1186 over rlCost, and gipuma_getview :1188-1213, after an iteration: every pixel, bit for bit"""
+@pytest.mark.parametrize("fast", [False, True])
+def test_lrdiff_operation_for_operation(fast):
+    """gipuma_getlrdiff :1160-1186 over rlCost, and gipuma_getview :1188-1213, after an iteration: every pixel, bit for bit — in the
+    reference's arithmetic and in the default one, where rlCost takes ONE liberty (the reciprocal of S7 (1))"""
     import ctypes as C
-    sc, orc = _scene_and_oracle(nofma=True, w=44, h=32, views=4, box=7, n_best=1)
+    sc, orc = _scene_and_oracle(nofma=True, w=44, h=32, views=4, box=7, n_best=1, flags=ol.FLAGS_FAST_8BIT_IMAGERY if fast else 0)
+    table = None
+    if fast:
+        table = _rcp_table_correctly_rounded()
+        orc.set_rcp_table(table)
     ptrs = [im.ctypes.data_as(C.c_void_p) for im in orc.images]
     orc.L.orc_bilinear.restype = C.c_float
     orc.L.orc_expf.restype = C.c_float
@@ -588,7 +599,7 @@ def test_lrdiff_operation_for_operation():
         for x in range(orc.w):
             if not (1 <= bv[y, x] <= 4):
                 continue                                                    # (no accepted hypothesis yet: the build leaves lrdiff as it is)
-            rc = rl_cost_f32(orc, ptrs, int(bv[y, x]), x, y, planes[y, x], 3, 3)
+            rc = rl_cost_f32(orc, ptrs, int(bv[y, x]), x, y, planes[y, x], 3, 3, rcp_table=table)
             d = abs(cost[y, x] - rc)
             d = f32(1) if d > f32(1) else d
             assert np.array([d], np.float32).view(np.uint32)[0] == orc.lrdiff[y, x:x + 1].view(np.uint32)[0], (x, y, d, orc.lrdiff[y, x])
