@@ -901,3 +901,26 @@ def test_fast_arithmetic_is_the_text_plus_its_seven_liberties(rows):
                 assert np.array([c], np.float32).view(np.uint32)[0] == np.array([got], np.float32).view(np.uint32)[0], (x, y, v, c, got)
                 checked += c < f32(2)
     assert checked > 100 and not orc.rcp_out_of_range
+
+
+def test_even_box_init_scores_on_box_over_two():
+    """gipuma_init_cu2 takes box / 2 as its window radius (gipuma.cu:693-694), the sweeps (box - 1) / 2 (:858-859): with an even box the
+    initial costs come from a larger window than every later one"""
+    import ctypes as C
+    sc, orc = _scene_and_oracle(nofma=True, w=30, h=24, views=3, box=8, n_best=1)
+    ptrs = [im.ctypes.data_as(C.c_void_p) for im in orc.images]
+    orc.L.orc_bilinear.restype = C.c_float
+    orc.L.orc_expf.restype = C.c_float
+    cam = _Cam(orc.camera(0))
+    _, n_init = random_init(orc, cam, seed=77)          # (its costs use the sweeps' radius: not compared here)
+    orc.pm_init()
+    assert np.array_equal(orc.norm4.view(np.uint32), n_init.view(np.uint32))
+    differ = 0
+    for y in range(0, orc.h, 3):
+        for x in range(0, orc.w, 3):
+            big = multiview_f32([pm_cost_f32(orc, ptrs, v, x, y, n_init[y, x], 4, 4) for v in (1, 2, 3)], [1, 2, 3], 1)[0]
+            small = multiview_f32([pm_cost_f32(orc, ptrs, v, x, y, n_init[y, x], 3, 3) for v in (1, 2, 3)], [1, 2, 3], 1)[0]
+            assert orc.c[y, x] == big, (x, y, orc.c[y, x], big, small)
+            assert f32(orc.pm_cost_multiview(x, y, n_init[y, x])[0]) == small
+            differ += big != small
+    assert differ > 20
